@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""bench.py - rollout-scored sentences/sec of the MI355X rollout-reward path.
+
+A "step" is one Model.get_reward pass (reference model.py:291-346) over one synthetic batch whose
+inputs are already resident in HBM: encoder, teacher-forced prefix pass, rollnum x (T-1) Monte-Carlo
+rollouts per sentence (KV-cached lock-step decoding + CDF-inversion sampling with injected
+uniforms), discriminator scoring of every rollout, per-prefix reward averaging, and - for N > 1 -
+the RCCL all-gather of the reward rows.  Weak scaling: every rank (one process per GPU) owns
+`batch` sentences; the global batch is batch x N and uniforms are indexed by global sentence id.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case (parity-test sized)
+    "c1": dict(name="transformer-small d256 N2 h4, B8 R4 T30 V32k", d=256, blocks=2, heads=4, batch=8, rollnum=4,
+               T=30, V=32000, E=256),
+    # BASELINE.json configs[1]: the configuration the metric is quoted on (default)
+    "c2": dict(name="transformer-base d512 N6 h8, B64 R16 T50 V32k", d=512, blocks=6, heads=8, batch=64, rollnum=16,
+               T=50, V=32000, E=512),
+    # BASELINE.json configs[3] per-GPU share (d=1024, 16 heads, R20, T80)
+    "c4": dict(name="transformer-big d1024 N6 h16, B8 R20 T80 V32k", d=1024, blocks=6, heads=16, batch=8, rollnum=20,
+               T=80, V=32000, E=512),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
+
+
+class Cfg(dict):
+    __getattr__ = dict.get
+
+
+def algorithmic_work(cfg, plan, B, Ls, es):
+    """Algorithmic FLOPs / bytes per kernel class for ONE get_reward (SURVEY section 8d figures;
+    derivation in DESIGN.md section 5)."""
+    d, N, T, V, E, R = cfg["d"], cfg["blocks"], cfg["T"], cfg["V"], cfg["E"], cfg["rollnum"]
+    live = plan.live.astype(np.int64)
+    step_rows = int(live[1:].sum())
+    dec_rows = step_rows + B * T                       # rollout steps + teacher-forced pass
+    enc_rows = B * Ls
+    widths = list(range(1, T, 4))
+    nf = [100 + 10 * w for w in widths]
+    F = sum(nf)
+    conv_per_row = sum(2 * (T - w + 1) * w * E * n for w, n in zip(widths, nf))
+    scored = plan.n_rows + 2 * B                       # rollouts + y_sample + source tower
+    kv_entry = 2 * d * es                              # one K + one V vector
+    # sharing-aware KV bytes of the rollout self-attention: per (group, step, block) the shared prefix
+    # once (g+1 entries) + every row's private suffix (s entries each)
+    g_of_group = plan.row_g[::R].astype(np.int64)
+    steps_of_group = (plan.lens[plan.row_b[::R]] - 1 - g_of_group)
+    self_entries = 0
+    for s in range(1, plan.n_steps + 1):
+        alive = steps_of_group >= s
+        self_entries += int((g_of_group[alive] + 1).sum()) + int(alive.sum()) * R * s
+    cross_entries = sum(int(np.unique(plan.row_b[:live[s]]).size) * Ls for s in range(1, plan.n_steps + 1))
+    return {
+        "gemm_proj": ("mfma", (12 * d * d * N) * dec_rows + (8 * d * d * N + 4 * d * d * N) * enc_rows),
+        "gemm_ffn": ("mfma", (16 * d * d * N) * (dec_rows + enc_rows)),
+        "gemm_logits": ("mfma", 2 * d * V * dec_rows),
+        "gemm_conv": ("mfma", conv_per_row * scored),
+        "gemm_highway": ("mfma", 4 * F * F * scored),
+        "sampler": ("hbm", (plan.n_rows + step_rows) * (4 * V + 8)),
+        "attn_self_step": ("hbm", N * kv_entry * self_entries),
+        "attn_cross_step": ("hbm", N * kv_entry * cross_entries),
+    }
+
+
+def cpu_baseline(cfg, Wg, Wd, x, y, seed_u):
+    """Reference-structured CPU path (the oracle's structure-faithful torch-CPU fp32 restatement: full
+    re-decode per sampled token, all-position logits, encoder + source tower per call) timed on the
+    host cores on a BOUNDED sample, extrapolated by exact (roll, give_num) counts."""
+    import torch
+    from oracle import nmtgan_oracle as O
+    T, R = cfg["T"], cfg["rollnum"]
+    Bc = 2 if cfg["d"] >= 512 else 4
+    gcfg = O.GenConfig(hidden_units=cfg["d"], num_blocks=cfg["blocks"], num_heads=cfg["heads"],
+                       src_vocab_size=cfg["V"], dst_vocab_size=cfg["V"])
+    dcfg = O.DisConfig(max_len=T, dim_word=cfg["E"], vocab_size=cfg["V"], vocab_size_s=cfg["V"])
+    W32, Wd32 = O.to_torch(Wg, torch.float32), O.to_torch(Wd, torch.float32)
+    xs, ys = x[:Bc], y[:Bc]
+    mask = np.ones_like(ys, dtype=np.float32)
+    xp = O.extend_sentence_to_maxlen(xs, T)
+    u = np.random.default_rng(seed_u).random((1, T - 1, Bc, T), dtype=np.float32)
+    gs = sorted({T - 1, max(1, T - 1 - (T - 1) // 12), max(1, T - 1 - (T - 1) // 6)})   # 1, ~T/12+1, ~T/6+1 sampled steps
+    pts = []
+    t_all = time.perf_counter()
+    with torch.no_grad():
+        for g in gs:
+            t0 = time.perf_counter()
+            O.get_reward(W32, gcfg, Wd32, dcfg, xs, xp, ys, mask, 1, T, 0.6, u, mode="full", pairs={(0, g)})
+            pts.append((T - g, time.perf_counter() - t0))
+    elapsed = time.perf_counter() - t_all
+    # each timed call = 1 rollout call of (T-g) sampled steps + 2 discriminator calls (the pair's and the
+    # per-roll y_sample one); fit t = a + b*(T-g) and sum over g = 1..T-1 for one roll
+    n = np.array([p[0] for p in pts], np.float64)
+    t = np.array([p[1] for p in pts], np.float64)
+    b, a = np.polyfit(n, t, 1) if len(pts) > 1 else (t[0] / n[0], 0.0)
+    per_roll = sum(a + b * (T - g) for g in range(1, T))
+    total = R * per_roll
+    return {"value": Bc / total, "unit": "rollout-scored sentences/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "oracle structure-faithful fp32 torch-CPU, %d sentences, 1 roll, give_num in %s "
+                      "(%.1f s measured), linear fit in sampled steps, extrapolated to rollnum %d x %d prefixes"
+                      % (Bc, gs, elapsed, R, T - 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=None, help="sentences per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--logits-chunk", type=int, default=None)
+    ap.add_argument("--disc-chunk", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+
+    import nmt_gan_amd as N
+    from nmt_gan_amd import _lib, synthetic
+    from nmt_gan_amd.model import gather_rows
+    from nmt_gan_amd.share_function import split_bounds
+
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["batch"] = args.batch
+    d, T, V, R, Bl = cfg["d"], cfg["T"], cfg["V"], cfg["rollnum"], cfg["batch"]
+    Bg = Bl * world
+    Wg = synthetic.generator_weights(d, cfg["blocks"], V, V, seed=0)
+    Wd = synthetic.discriminator_weights(T, cfg["E"], V, V, seed=1)
+    widths, nfs = synthetic.disc_filters(T)
+    mcfg = Cfg(hidden_units=d, num_blocks=cfg["blocks"], num_heads=cfg["heads"], src_vocab_size=V, dst_vocab_size=V,
+               scale_embedding=True, residual_dropout_rate=0.0, train=Cfg(shared_embedding=False))
+    model = N.Model(mcfg, precision=args.precision, device=str(dev))
+    model.build_train_model()
+    model.build_generate(T)
+    model.build_rollout_generate(T)
+    model.init_and_restore(weights=Wg)
+    disc = N.DisCNN(None, T, 2, V, Bl, cfg["E"], widths, nfs, vocab_size_s=V, precision=args.precision, device=str(dev))
+    disc.load_weights(Wd)
+    if args.logits_chunk:
+        model.logits_chunk_rows = args.logits_chunk
+    if args.disc_chunk:
+        model.disc_chunk_rows = args.disc_chunk
+
+    x, y = synthetic.synthetic_batch(Bg, T, V, V, seed=1234)         # no </S>: every row full length T
+    y, mask = N.deal_generated_samples(y)
+    xp = N.extend_sentence_to_maxlen(x, T)
+    bounds = split_bounds(Bg, world)
+    b0, b1 = bounds[rank], bounds[rank + 1]
+    u = model.make_uniforms(R, T, Bg, seed=2024)                      # Philox, resident in HBM
+    prep = model.prepare_reward(x[b0:b1], xp[b0:b1], y[b0:b1], mask[b0:b1], R, disc, T, 0.6, u, b_offset=b0,
+                                B_global=Bg)
+
+    def step():
+        r = prep.launch()
+        return gather_rows(r, bounds, dev) if world > 1 else r
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert bool(torch.isfinite(out).all())
+
+    result = {
+        "metric": "rollout-scored sentences/sec (rollnum=16, len 50)" if args.config == "c2"
+        else "rollout-scored sentences/sec (rollnum=%d, len %d)" % (R, T),
+        "value": Bg * args.steps / elapsed, "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": cfg["name"], "config_id": args.config, "global_batch": Bg, "batch_per_gpu": Bl,
+                   "rollnum": R, "max_len": T, "vocab": V, "rollouts_per_step": int(prep.plan.n_rows) * world,
+                   "sampled_tokens_per_step": int(prep.plan.n_rows + prep.plan.live[1:].sum()) * world,
+                   "parallelism": "sentence-sharded x%d, RCCL all-gather of rewards" % world if world > 1 else "single GPU",
+                   "workspace_GiB": round(prep.workspace_bytes / 2 ** 30, 2)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        ncls = _lib.lib.nmtgan_profile_classes()
+        ms = (C.c_double * ncls)()
+        cnt = (C.c_int64 * ncls)()
+        _lib.lib.nmtgan_profile_start()
+        step()
+        _lib.check(_lib.lib.nmtgan_profile_stop(ms, cnt, ncls), "profile_stop")
+        work = algorithmic_work(cfg, prep.plan, Bl, x.shape[1], 2 if args.precision == "bf16" else 4)
+        rows = {}
+        for i, name in enumerate(_lib.PROFILE_CLASSES):
+            if cnt[i] == 0:
+                continue
+            row = {"launches": int(cnt[i]), "ms": round(ms[i], 3), "avg_us": round(1e3 * ms[i] / cnt[i], 2)}
+            if name in work:
+                bound, amount = work[name]
+                if bound == "mfma":
+                    row.update(bound="mfma", achieved=round(amount / (ms[i] * 1e-3) / 1e12, 2),
+                               peak=MFMA_PEAK_TF[args.precision], unit="TFLOP/s")
+                else:
+                    row.update(bound="hbm", achieved=round(amount / (ms[i] * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
+                               unit="GB/s")
+                row["frac"] = round(row["achieved"] / row["peak"], 4)
+                row["algorithmic_per_step"] = amount
+            rows[name] = row
+        top = max((k for k in rows if "bound" in rows[k]), key=lambda k: rows[k]["ms"])
+        r = rows[top]
+        result["roofline"] = {"kernel": top, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
+                              "unit": r["unit"], "frac": r["frac"], "traffic": None,
+                              "launches": r["launches"], "avg_launch_us": r["avg_us"],
+                              "note": "HIP events around every launch of one extra (untimed) step; achieved = "
+                                      "algorithmic work of the class / summed launch time"}
+        result["roofline_all"] = rows
+        result["profiled_step_ms"] = round(float(sum(ms)), 2)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, Wg, Wd, x, y, 99)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

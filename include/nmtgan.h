@@ -1,0 +1,301 @@
+/* nmtgan.h - C ABI of libnmtgan_hip.so: the MI355X (gfx950) rollout-reward path of NMT_GAN.
+ *
+ * The reference (ZhenYangIACAS/NMT_GAN) has no FFI/plugin interface: its boundary is the Python
+ * method surface gan_train.py calls (Model.get_reward model.py:291, Model.generate_step
+ * model.py:268, the DisCNN feed/fetch of model.py:311-313).  nmt_gan_amd/ keeps that surface and
+ * binds the entry points below with ctypes; every entry point cites the reference code it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - all pointers are BORROWED device pointers unless a field says "host"; nothing is retained
+ *    past the call, nothing is freed.  The caller owns the workspace.
+ *  - every call enqueues asynchronously on `stream` (a hipStream_t passed as void*) and never
+ *    synchronises; no hipMalloc/hipFree inside.
+ *  - return 0 on success, a negative code on error; nmtgan_last_error() gives the thread-local
+ *    message.  Shapes are validated on the host before any launch.
+ *  - "op dtype" = the MFMA operand / KV-cache / activation-copy element type of a packed model:
+ *    NMTGAN_BF16 (bf16 operands, fp32 accumulate; the throughput tier) or NMTGAN_F32 (exact fp32
+ *    MFMA; the 1e-5 parity tier).  Residual stream, LayerNorm, softmax, CDF are fp32/fp64 always.
+ *  - weight matrices are stored TRANSPOSED, Wt[N][K] K-contiguous (TF stores kernel[K][N]); the
+ *    Python facade repacks once at load time.
+ */
+#ifndef NMTGAN_H_
+#define NMTGAN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMTGAN_VERSION 1
+#define NMTGAN_BF16 0
+#define NMTGAN_F32 1
+#define NMTGAN_MAX_BLOCKS 16
+#define NMTGAN_MAX_WIDTHS 32
+
+int nmtgan_version(void);
+const char* nmtgan_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = A[M,K] . Wt[N,K]^T  (+ epilogue).  Replaces tf.layers.conv2d 1x1 (= dense+bias,
+ * common_layers.py:284-290; call sites common_attention.py:372-387,397, common_layers.py:1093-1106),
+ * tf.matmul(.,E^T) (model.py:811/818), tf.nn.conv2d VALID over time (cnn_discriminator.py:94-99)
+ * and the highway/linear matmuls (cnn_discriminator.py:35-48).
+ * A row r lives at A + ((r / a_group) * a_group_stride + (r % a_group) * lda) elements; a_group<=0
+ * means plain rows (r*lda).  For the discriminator conv of width w: a_group = T-w+1, lda = E,
+ * a_group_stride = T*E, K = w*E (a window is a contiguous slice of the [T,E] sentence image).
+ * epilogue NMTGAN_EPI_LINEAR : v = (acc + bias[n]) * seg_scale[s]; relu optional; column segment
+ *      s = n / seg_width goes to out[s] (row stride ldo[s], dtype out_f32[s] ? fp32 : op dtype).
+ * epilogue NMTGAN_EPI_CONVMAX: v = relu(acc*scale[n] + shift[n]) (conv bias + inference BN folded,
+ *      cnn_discriminator.py:100-105,22-33); pooled[(r / a_group)*ld_pool + n] = max(., v) - the
+ *      max over time of cnn_discriminator.py:469.  pooled must be >= 0 on entry (memset 0).
+ */
+#define NMTGAN_EPI_LINEAR 0
+#define NMTGAN_EPI_CONVMAX 1
+typedef struct {
+  int op_dtype;              /* NMTGAN_BF16 / NMTGAN_F32 for A and Wt */
+  int epilogue;
+  const void* A;
+  const void* Wt;            /* [N][K] */
+  int M, N, K;
+  int64_t lda;
+  int a_group;
+  int64_t a_group_stride;
+  /* LINEAR */
+  const float* bias;         /* [N] or NULL */
+  int relu;
+  int n_seg;                 /* 1..3 */
+  int seg_width;             /* columns per segment (multiple of 32 when n_seg>1) */
+  void* out[3];
+  int64_t ldo[3];
+  int out_f32[3];
+  float seg_scale[3];
+  /* CONVMAX */
+  const float* scale;        /* [N] */
+  const float* shift;        /* [N] */
+  float* pooled;
+  int64_t ld_pool;
+} nmtgan_gemm_args;
+int nmtgan_gemm(const nmtgan_gemm_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding: out[r] = mult * table[tok(r)] + timing[pos(r)]   (fp32 and op-dtype copies).
+ * Replaces tf.gather + scale + add_timing_signal_1d (model.py:777-801, 506, 565;
+ * common_attention.py:55-68).  Decoder passes mult = 2*sqrt(d) (model.py:565 adds x twice).
+ * tok(r) = tok[r*tok_ld + (tok_col ? tok_col[r] : 0) + tok_col_add]
+ * pos(r) = (pos ? pos[r] : r % pos_mod) + pos_add
+ */
+typedef struct {
+  const float* table;        /* [V][d] fp32 */
+  const float* timing;       /* [max_pos][d] fp32 */
+  int vocab, max_pos;
+  const int32_t* tok; int64_t tok_ld; const int32_t* tok_col; int tok_col_add;
+  const int32_t* pos; int pos_mod; int pos_add;
+  float mult;
+  int M, d;
+  float* out_f32;            /* [M][d] */
+  void* out_op;              /* [M][d] op dtype, may be NULL */
+  int op_dtype;
+} nmtgan_embed_args;
+int nmtgan_embed(const nmtgan_embed_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * out = LayerNorm(x + y) * gamma + beta, eps 1e-6, biased variance
+ * (model.py:725-739 residual(); common_layers.py:336-341,359-374).  Optional zero_row[r] != 0
+ * zeroes the output row (encoder padding, model.py:542).
+ */
+typedef struct {
+  const float* x; const float* y;      /* [M][d] fp32; y may be NULL */
+  const float* gamma; const float* beta;
+  int M, d;
+  float* out_f32; void* out_op; int op_dtype;
+  const uint8_t* zero_row;
+} nmtgan_addln_args;
+int nmtgan_add_layernorm(const nmtgan_addln_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row attention: one query row against (1) a block of shared keys and (2) its private suffix.
+ * Replaces dot_product_attention (common_attention.py:294-331) for: encoder self-attention
+ * (padding mask), decoder causal self-attention (prefill and the incremental rollout step),
+ * decoder-encoder attention.  q is already scaled by dk^-0.5 (common_attention.py:393).
+ * Segment 1: keys j in [0, cnt1(r)) at k1 + (blk(r)*len1 + j)*d, skipped where
+ *            mask1[blk(r)*len1 + j] != 0 (the -1e9 padding bias, common_attention.py:192-202).
+ *            blk(r) = seg1_blk ? seg1_blk[r] : r / rows_per_blk
+ *            cnt1(r) = seg1_cnt ? seg1_cnt[r] : (causal ? r % rows_per_blk + 1 : len1)
+ *            (the causal form is the lower-triangle bias, common_attention.py:178-189)
+ * Segment 2: keys s in [0, n_steps2) at k2 + (step_off[s] + r)*d  (step-major private cache).
+ */
+typedef struct {
+  const float* q;            /* [M][d] fp32 */
+  int M, d, heads;
+  int kv_dtype;              /* dtype of k1,v1,k2,v2 and out */
+  const void* k1; const void* v1; int len1;
+  const int32_t* seg1_blk; const int32_t* seg1_cnt; int rows_per_blk; int causal;
+  const uint8_t* mask1;
+  const void* k2; const void* v2; const int64_t* step_off; int n_steps2;
+  void* out;                 /* [M][d] kv_dtype */
+} nmtgan_attn_args;
+int nmtgan_attn_rows(const nmtgan_attn_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Categorical sampler with injected uniforms.  Replaces softmax -> log -> tf.multinomial(.,1)
+ * (model.py:235-241).  out[r] = min{k : c_k > u(r) * c_{V-1}}, c_k = sum_{j<=k} exp(l_j - max l)
+ * accumulated in fp64 (TF CPU kernel semantics), clamped to V-1.  exp is evaluated in fp32 and
+ * widened (the CPU kernel evaluates it in fp64): buckets agree except within ~1e-7 relative of a
+ * CDF boundary.
+ * logits row of r = row_map ? row_map[r] : r;  u(r) = u[(u_off ? u_off[r] : r) + u_add].
+ * greedy != 0: out[r] = first argmax (model.py:153-154) and u is ignored.
+ */
+typedef struct {
+  const float* logits; int64_t ld; int V; int M;
+  const int32_t* row_map;
+  const float* u; const int64_t* u_off; int64_t u_add;
+  int greedy;
+  int32_t* out;
+} nmtgan_sample_args;
+int nmtgan_sample_rows(const nmtgan_sample_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Packed models.  All matrices Wt[N][K] in op dtype; biases / LN / BN-folded vectors fp32.
+ */
+typedef struct {
+  const void* w; const float* b;       /* Wt[N][K], bias[N] */
+} nmtgan_dense;
+typedef struct { const float* g; const float* b; } nmtgan_ln;
+typedef struct {
+  nmtgan_dense qkv, o, ffn1, ffn2;     /* [3d,d] [d,d] [4d,d] [d,4d] */
+  nmtgan_ln ln0, ln1;
+} nmtgan_enc_block;
+typedef struct {
+  nmtgan_dense qkv, o, cq, ckv, co, ffn1, ffn2;   /* self / cross(q [d,d], kv [2d,d], o) / ffn */
+  nmtgan_ln ln0, ln1, ln2;
+} nmtgan_dec_block;
+typedef struct {                       /* Model weights (model.py:486-618, 772-820) */
+  int op_dtype;
+  int d, heads, n_blocks, vocab_src, vocab_dst;
+  float emb_mult;                      /* sqrt(d) if scale_embedding else 1 (model.py:494,553) */
+  const float* emb_src;                /* [Vs][d] fp32 */
+  const float* emb_dst;                /* [Vt][d] fp32 */
+  const void* softmax_w;               /* [Vt][d] op dtype (already [N][K]) */
+  const float* timing; int max_pos;    /* [max_pos][d] fp32 */
+  nmtgan_enc_block enc[NMTGAN_MAX_BLOCKS];
+  nmtgan_dec_block dec[NMTGAN_MAX_BLOCKS];
+} nmtgan_generator;
+
+typedef struct {                       /* one tower of DisCNN (cnn_discriminator.py:454-482) */
+  const void* emb;                     /* [V][E] op dtype */
+  const void* conv_w[NMTGAN_MAX_WIDTHS];     /* Wt[n_w][w*E] */
+  const float* conv_scale[NMTGAN_MAX_WIDTHS];/* gamma*rsqrt(var+1e-3) */
+  const float* conv_shift[NMTGAN_MAX_WIDTHS];/* (b-mean)*scale+beta */
+  const void* hw_out;                  /* Wt[Fp][Fp] zero padded */
+  const void* hw_tr;                   /* Wt[Fp][Fp] */
+} nmtgan_disc_tower;
+typedef struct {                       /* DisCNN inference weights */
+  int op_dtype;
+  int max_len, dim_word, vocab, vocab_s;
+  int n_widths; int widths[NMTGAN_MAX_WIDTHS]; int n_filters[NMTGAN_MAX_WIDTHS];
+  int F, Fp;                           /* sum n_filters; Fp = F rounded up to 64 */
+  nmtgan_disc_tower tgt, src;
+  const float* head_w;                 /* [2][2*Fp] fp32: class-major, [tgt Fp | src Fp] */
+  const float* head_b;                 /* [2] */
+} nmtgan_discriminator;
+
+/* ------------------------------------------------------------------------------------------
+ * Discriminator inference.  Replaces sess.run(disc.dis_ypred_for_auc, {dis_input_x, dis_input_xs,
+ * dis_dropout_keep_prob: 1.0}) (model.py:311-313 -> cnn_discriminator.py:529-558, 440-522).
+ * nmtgan_disc_features: ids[M][T] (batch-major) -> highway features feat[M][Fp] fp32 of one tower.
+ * nmtgan_disc_head: p_real[r] = softmax([feat_t[r] | feat_s[src_row ? src_row[r] : r]].W + b)[1].
+ * Both chunk internally; workspace from nmtgan_disc_workspace_bytes(disc, chunk_rows).
+ */
+size_t nmtgan_disc_workspace_bytes(const nmtgan_discriminator* d, int chunk_rows);
+int nmtgan_disc_features(const nmtgan_discriminator* d, int source_tower, const int32_t* ids, int M,
+                         float* feat, int chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
+int nmtgan_disc_head(const nmtgan_discriminator* d, const float* feat_t, const float* feat_s,
+                     const int32_t* src_row, int M, float* p_real, float* probs2, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-prefix reward averaging.  Replaces the numpy tail of Model.get_reward (model.py:315-345):
+ * Q[b,g-1] = sum_r p[grp_first[b,g-1] + r] (rolls added in r order) or rollnum adds of p_base[b]
+ * when grp_first < 0 (prefix >= sentence length); Q[b,T-1] = rollnum adds of p_base[b];
+ * rewards = ((Q - bias_num*rollnum) * mask) / rollnum   (bias skipped when use_bias == 0).
+ */
+int nmtgan_reward_reduce(const float* p, const float* p_base, const int32_t* grp_first,
+                         const float* mask, int B, int T, int rollnum, int use_bias, double bias_num,
+                         float* rewards, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The hot path: Model.get_reward (model.py:291-346) = rollout graph (model.py:203-266) +
+ * discriminator graph, restructured: encoder once, teacher-forced prefix pass once, KV-cached
+ * lock-step rollouts over all live (sentence, roll, prefix) rows, source tower once.
+ * The plan (row order, live counts) is built by the host facade; rows are sorted by remaining
+ * private steps (descending) so the live rows of step s are the prefix [0, live[s]).
+ */
+typedef struct {
+  int B, Ls, T, rollnum;
+  int n_rows;                       /* live rollouts: rows (b, r, g) with 1 <= g < len_b */
+  int n_steps;                      /* max private steps = max_b(len_b) - 2 (>= 0) */
+  const int32_t* live;              /* HOST [n_steps+1]: live[0] = n_rows, live[s] rows at step s */
+  const int64_t* step_off_host;     /* HOST [n_steps+1]: cumulative rows of steps 1..s */
+  const int64_t* step_off;          /* device copy of step_off_host */
+  const int32_t* x;                 /* [B][Ls] source ids */
+  const uint8_t* x_pad;             /* [B][Ls] 1 where x == 0 */
+  const int32_t* x_pad_to_T;        /* [B][T] source ids zero-extended to T (share_function.py:240-245) */
+  const int32_t* y;                 /* [B][T] y_sample (zero from </S> on) */
+  const int32_t* dec_in;            /* [B][T] shift_right(y) (model.py:764-766) */
+  const float* mask;                /* [B][T] y_sample_mask (prefix of ones) */
+  const int32_t* row_b;             /* [n_rows] sentence of row */
+  const int32_t* row_g;             /* [n_rows] give_num of row */
+  const int32_t* row_gp1;           /* [n_rows] give_num + 1 (shared keys of row) */
+  const int32_t* row_lrow;          /* [n_rows] b*T + g: prefix-pass logits row of the first sample */
+  const int64_t* row_uoff;          /* [n_rows] offset of u[r, g-1, b, g] in uniforms */
+  const int32_t* grp_first;         /* [B][T-1] first row of group (b,g) or -1 */
+  const float* uniforms;            /* [R][T-1][B_global][T] */
+  int use_bias; double bias_num;    /* bias array = float32(bias_num * rollnum), model.py:340-341 */
+  int logits_chunk_rows;            /* rows per logits GEMM + sampler chunk */
+  int disc_chunk_rows;
+  float* rewards;                   /* out [B][T] fp32 */
+  int32_t* rollouts;                /* out [n_rows][T] masked rollouts (debug/parity), may be NULL */
+  float* p_rows;                    /* out [n_rows] P(real) per rollout, may be NULL */
+  float* p_base;                    /* out [B] P(real) of y_sample itself, may be NULL */
+  float* prefix_logits;             /* out [B][T][V] teacher-forced logits, may be NULL */
+} nmtgan_reward_plan;
+size_t nmtgan_rollout_reward_workspace_bytes(const nmtgan_generator* g, const nmtgan_discriminator* d,
+                                             const nmtgan_reward_plan* plan);
+int nmtgan_rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d,
+                          const nmtgan_reward_plan* plan, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Greedy generation.  Replaces sess.run(generate_sample) (model.py:140-176, 268-271): KV-cached,
+ * argmax per position, no early stop.  x [B][Ls], x_pad [B][Ls] -> y [B][T].
+ */
+size_t nmtgan_generate_workspace_bytes(const nmtgan_generator* g, int B, int Ls, int T);
+int nmtgan_generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_pad, int B, int Ls,
+                           int T, int32_t* y, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Teacher-forced logits [B][T][V] of decoder(shift_right(y)) - parity hook for the encoder/decoder
+ * stack (model.py:486-618 + top, model.py:804-820). */
+size_t nmtgan_teacher_forced_workspace_bytes(const nmtgan_generator* g, int B, int Ls, int T);
+int nmtgan_teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_pad,
+                                 const int32_t* dec_in, int B, int Ls, int T, float* logits,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement hook (no counterpart in the reference; used by bench.py's roofline leg only).
+ * Between start and stop every kernel launch is bracketed by HIP events on its own stream;
+ * stop synchronises the device and returns summed milliseconds and launch counts per class:
+ * 0 other, 1 gemm_proj (QKV/out/cross projections), 2 gemm_ffn, 3 gemm_logits, 4 gemm_conv
+ * (discriminator conv+BN+ReLU+max), 5 gemm_highway, 6 attn_self_step, 7 attn_cross_step,
+ * 8 attn_prefill (encoder + teacher-forced pass), 9 sampler, 10 add_layernorm, 11 embed,
+ * 12 disc_small (gather/cast/gate/head/reduce).  Allocates events: never use inside timed runs.
+ */
+int nmtgan_profile_classes(void);
+int nmtgan_profile_start(void);
+int nmtgan_profile_stop(double* ms_per_class, int64_t* launches_per_class, int n_classes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMTGAN_H_ */

@@ -1,0 +1,138 @@
+// extern "C" surface of libnmtgan_hip.so (declared in include/nmtgan.h).
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace nmtgan {
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+namespace prof {
+bool g_on = false;
+thread_local int g_hint = -1;
+struct Rec { int cls; hipEvent_t a, b; };
+static std::vector<Rec> g_recs;
+void begin(int cls, hipStream_t st) {
+  Rec r{cls, nullptr, nullptr};
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+}
+void end(hipStream_t st) {
+  if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, st);
+}
+}  // namespace prof
+int disc_workspace(const nmtgan_discriminator* d, int chunk, size_t* bytes);
+int disc_features(const nmtgan_discriminator* d, int source, const int32_t* ids, int M, float* feat, int chunk,
+                  void* ws, size_t ws_bytes, hipStream_t st);
+int reward_workspace(const nmtgan_generator* g, const nmtgan_discriminator* d, const nmtgan_reward_plan* p,
+                     size_t* bytes);
+int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, const nmtgan_reward_plan* p, void* ws,
+                   size_t ws_bytes, hipStream_t st);
+int teacher_forced_workspace(const nmtgan_generator* g, int B, int Ls, int T, size_t* bytes);
+int teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_pad, const int32_t* dec_in,
+                          int B, int Ls, int T, float* logits, void* ws, size_t ws_bytes, hipStream_t st);
+int generate_workspace(const nmtgan_generator* g, int B, int Ls, int T, size_t* bytes);
+int generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_pad, int B, int Ls, int T,
+                    int32_t* y, void* ws, size_t ws_bytes, hipStream_t st);
+}  // namespace nmtgan
+
+using namespace nmtgan;
+
+extern "C" {
+
+int nmtgan_version(void) { return NMTGAN_VERSION; }
+const char* nmtgan_last_error(void) { return g_err.c_str(); }
+
+int nmtgan_profile_classes(void) { return prof::N_CLS; }
+int nmtgan_profile_start(void) {
+  prof::g_recs.clear();
+  prof::g_on = true;
+  return 0;
+}
+int nmtgan_profile_stop(double* ms_per_class, int64_t* launches_per_class, int n_classes) {
+  prof::g_on = false;
+  if (hipDeviceSynchronize() != hipSuccess) { set_error("profile_stop: device synchronize failed"); return -3; }
+  for (int i = 0; i < n_classes; ++i) { ms_per_class[i] = 0.0; launches_per_class[i] = 0; }
+  for (auto& r : prof::g_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.cls >= 0 && r.cls < n_classes) {
+      ms_per_class[r.cls] += ms;
+      launches_per_class[r.cls] += 1;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  prof::g_recs.clear();
+  return 0;
+}
+
+int nmtgan_gemm(const nmtgan_gemm_args* a, void* stream) { return launch_gemm(a, (hipStream_t)stream); }
+int nmtgan_embed(const nmtgan_embed_args* a, void* stream) { return launch_embed(a, (hipStream_t)stream); }
+int nmtgan_add_layernorm(const nmtgan_addln_args* a, void* stream) {
+  return launch_add_layernorm(a, (hipStream_t)stream);
+}
+int nmtgan_attn_rows(const nmtgan_attn_args* a, void* stream) { return launch_attn_rows(a, (hipStream_t)stream); }
+int nmtgan_sample_rows(const nmtgan_sample_args* a, void* stream) {
+  return launch_sample_rows(a, (hipStream_t)stream);
+}
+
+size_t nmtgan_disc_workspace_bytes(const nmtgan_discriminator* d, int chunk_rows) {
+  size_t b = 0;
+  return disc_workspace(d, chunk_rows, &b) == 0 ? b : 0;
+}
+int nmtgan_disc_features(const nmtgan_discriminator* d, int source_tower, const int32_t* ids, int M, float* feat,
+                         int chunk_rows, void* workspace, size_t workspace_bytes, void* stream) {
+  return disc_features(d, source_tower, ids, M, feat, chunk_rows, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int nmtgan_disc_head(const nmtgan_discriminator* d, const float* feat_t, const float* feat_s,
+                     const int32_t* src_row, int M, float* p_real, float* probs2, void* stream) {
+  if (!d) { set_error("disc_head: null discriminator"); return -2; }
+  return launch_disc_head(feat_t, feat_s, src_row, M, d->Fp, d->head_w, d->head_b, p_real, probs2,
+                          (hipStream_t)stream);
+}
+int nmtgan_reward_reduce(const float* p, const float* p_base, const int32_t* grp_first, const float* mask, int B,
+                         int T, int rollnum, int use_bias, double bias_num, float* rewards, void* stream) {
+  return launch_reward_reduce(p, p_base, grp_first, mask, B, T, rollnum, use_bias, bias_num, rewards,
+                              (hipStream_t)stream);
+}
+
+size_t nmtgan_rollout_reward_workspace_bytes(const nmtgan_generator* g, const nmtgan_discriminator* d,
+                                             const nmtgan_reward_plan* plan) {
+  size_t b = 0;
+  return reward_workspace(g, d, plan, &b) == 0 ? b : 0;
+}
+int nmtgan_rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, const nmtgan_reward_plan* plan,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  return rollout_reward(g, d, plan, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t nmtgan_generate_workspace_bytes(const nmtgan_generator* g, int B, int Ls, int T) {
+  size_t b = 0;
+  return generate_workspace(g, B, Ls, T, &b) == 0 ? b : 0;
+}
+int nmtgan_generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_pad, int B, int Ls, int T,
+                           int32_t* y, void* workspace, size_t workspace_bytes, void* stream) {
+  return generate_greedy(g, x, x_pad, B, Ls, T, y, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t nmtgan_teacher_forced_workspace_bytes(const nmtgan_generator* g, int B, int Ls, int T) {
+  size_t b = 0;
+  return teacher_forced_workspace(g, B, Ls, T, &b) == 0 ? b : 0;
+}
+int nmtgan_teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_pad,
+                                 const int32_t* dec_in, int B, int Ls, int T, float* logits, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  return teacher_forced_logits(g, x, x_pad, dec_in, B, Ls, T, logits, workspace, workspace_bytes,
+                               (hipStream_t)stream);
+}
+
+}  // extern "C"

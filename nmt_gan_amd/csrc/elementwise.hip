@@ -1,0 +1,276 @@
+// Memory-bound row kernels of the rollout-reward path (gfx950): embedding + timing signal,
+// residual-add + LayerNorm, rollout token bookkeeping, discriminator gather / highway gate / head,
+// per-prefix reward averaging.  One wavefront per row where a row reduction is needed; every
+// global access is a contiguous 4-16 B per lane.
+#include "common.h"
+#include "kernels.h"
+
+namespace nmtgan {
+
+// ------------------------------------------------------------------ embedding (model.py:772-802, 506, 565)
+template <typename OpT>
+__global__ __launch_bounds__(256) void embed_kernel(nmtgan_embed_args a) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.M) return;
+  int tok = a.tok[(int64_t)r * a.tok_ld + (a.tok_col ? a.tok_col[r] : 0) + a.tok_col_add];
+  tok = min(max(tok, 0), a.vocab - 1);
+  int pos = (a.pos ? a.pos[r] : (a.pos_mod > 0 ? r % a.pos_mod : 0)) + a.pos_add;
+  pos = min(max(pos, 0), a.max_pos - 1);
+  const float* e = a.table + (int64_t)tok * a.d;
+  const float* s = a.timing + (int64_t)pos * a.d;
+  float* of = a.out_f32 + (int64_t)r * a.d;
+  OpT* oo = a.out_op ? reinterpret_cast<OpT*>(a.out_op) + (int64_t)r * a.d : nullptr;
+  for (int i = lane; i < a.d; i += 64) {
+    const float v = e[i] * a.mult + s[i];
+    of[i] = v;
+    if (oo) OpTraits<OpT>::store(oo + i, v);
+  }
+}
+
+int launch_embed(const nmtgan_embed_args* a, hipStream_t st) {
+  prof::Scope prof_scope(prof::EMBED, st);
+  NMTGAN_REQUIRE(a != nullptr, "embed: null args");
+  if (a->M == 0) return 0;
+  NMTGAN_REQUIRE(a->M > 0 && a->d > 0 && a->vocab > 0 && a->max_pos > 0, "embed: bad shape");
+  NMTGAN_REQUIRE(a->table && a->timing && a->tok && a->out_f32, "embed: null pointer");
+  dim3 grid((a->M + 3) / 4), block(256);
+  if (a->op_dtype == NMTGAN_BF16) hipLaunchKernelGGL(embed_kernel<bf16_t>, grid, block, 0, st, *a);
+  else if (a->op_dtype == NMTGAN_F32) hipLaunchKernelGGL(embed_kernel<float>, grid, block, 0, st, *a);
+  else NMTGAN_FAIL(-2, "embed: bad op_dtype %d", a->op_dtype);
+  NMTGAN_CHECK_LAUNCH("embed");
+  return 0;
+}
+
+// ------------------------------------------------------------------ residual + LayerNorm
+// (model.py:725-739; common_layers.py:336-341: mean, biased variance of (x-mean), rsqrt(var+1e-6))
+template <typename OpT, int EPL>
+__global__ __launch_bounds__(256) void addln_kernel(nmtgan_addln_args a) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.M) return;
+  const int64_t base = (int64_t)r * a.d + lane * EPL;
+  float v[EPL];
+  VecIO<float, EPL>::load(a.x + base, v);
+  if (a.y) {
+    float y[EPL];
+    VecIO<float, EPL>::load(a.y + base, y);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] += y[e];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) s += v[e];
+  const float mean = wave_sum(s) / (float)a.d;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+  const float var = wave_sum(q) / (float)a.d;
+  const float rs = rsqrtf(var + 1e-6f);
+  float g[EPL], b[EPL];
+  VecIO<float, EPL>::load(a.gamma + lane * EPL, g);
+  VecIO<float, EPL>::load(a.beta + lane * EPL, b);
+  const bool zero = a.zero_row && a.zero_row[r];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) v[e] = zero ? 0.f : (v[e] * rs) * g[e] + b[e];
+  if (a.out_f32) VecIO<float, EPL>::store(a.out_f32 + base, v);
+  if (a.out_op) VecIO<OpT, EPL>::store(reinterpret_cast<OpT*>(a.out_op) + base, v);
+}
+
+template <typename OpT>
+static int launch_addln_t(const nmtgan_addln_args& a, hipStream_t st) {
+  dim3 grid((a.M + 3) / 4), block(256);
+  switch (a.d / 64) {
+    case 1: hipLaunchKernelGGL((addln_kernel<OpT, 1>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((addln_kernel<OpT, 2>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((addln_kernel<OpT, 4>), grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL((addln_kernel<OpT, 8>), grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL((addln_kernel<OpT, 16>), grid, block, 0, st, a); break;
+    default: NMTGAN_FAIL(-2, "add_layernorm: d/64 must be 1,2,4,8 or 16 (d=%d)", a.d);
+  }
+  NMTGAN_CHECK_LAUNCH("add_layernorm");
+  return 0;
+}
+
+int launch_add_layernorm(const nmtgan_addln_args* a, hipStream_t st) {
+  prof::Scope prof_scope(prof::ADDLN, st);
+  NMTGAN_REQUIRE(a != nullptr, "add_layernorm: null args");
+  if (a->M == 0) return 0;
+  NMTGAN_REQUIRE(a->M > 0 && a->d > 0 && a->d % 64 == 0, "add_layernorm: bad M=%d d=%d", a->M, a->d);
+  NMTGAN_REQUIRE(a->x && a->gamma && a->beta && (a->out_f32 || a->out_op), "add_layernorm: null pointer");
+  if (a->op_dtype == NMTGAN_BF16) return launch_addln_t<bf16_t>(*a, st);
+  if (a->op_dtype == NMTGAN_F32) return launch_addln_t<float>(*a, st);
+  NMTGAN_FAIL(-2, "add_layernorm: bad op_dtype %d", a->op_dtype);
+}
+
+// ------------------------------------------------------------------ rollout tokens
+// Y[row][t] = y[b][t] for t < g else 0 (model.py:250-252: given_y = Y[:, :given_num], zero padded)
+__global__ void init_rollouts_kernel(const int32_t* y, const int32_t* row_b, const int32_t* row_g, int n_rows, int T,
+                                     int32_t* Y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_rows * T) return;
+  const int row = (int)(i / T), t = (int)(i % T);
+  Y[i] = t < row_g[row] ? y[(int64_t)row_b[row] * T + t] : 0;
+}
+int launch_init_rollouts(const int32_t* y, const int32_t* row_b, const int32_t* row_g, int n_rows, int T,
+                         int32_t* Y, hipStream_t st) {
+  prof::Scope prof_scope(prof::OTHER, st);
+  if (n_rows == 0) return 0;
+  const int64_t n = (int64_t)n_rows * T;
+  hipLaunchKernelGGL(init_rollouts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, row_b, row_g,
+                     n_rows, T, Y);
+  NMTGAN_CHECK_LAUNCH("init_rollouts");
+  return 0;
+}
+// Y[row][row_g[row] + add] = tok[row]  (model.py:242: append the sampled token)
+__global__ void scatter_tokens_kernel(const int32_t* tok, const int32_t* row_g, int add, int n, int T, int32_t* Y) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int t = row_g[r] + add;
+  if (t >= 0 && t < T) Y[(int64_t)r * T + t] = tok[r];
+}
+int launch_scatter_tokens(const int32_t* tok, const int32_t* row_g, int add, int n, int T, int32_t* Y,
+                          hipStream_t st) {
+  prof::Scope prof_scope(prof::OTHER, st);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scatter_tokens_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tok, row_g, add, n, T, Y);
+  NMTGAN_CHECK_LAUNCH("scatter_tokens");
+  return 0;
+}
+
+// ------------------------------------------------------------------ discriminator gather
+// tf.nn.embedding_lookup (cnn_discriminator.py:454, 485): out[i] = table[ids[i]]; 16 B per lane.
+__global__ __launch_bounds__(256) void disc_embed_kernel(const char* table, int vocab, const int32_t* ids,
+                                                         int64_t n_tok, int row_bytes, char* out) {
+  const int cpr = row_bytes >> 4;                       // 16-byte chunks per row
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tok * cpr) return;
+  const int64_t t = i / cpr;
+  const int c = (int)(i % cpr);
+  const int id = min(max(ids[t], 0), vocab - 1);
+  reinterpret_cast<uint4*>(out + t * row_bytes)[c] = reinterpret_cast<const uint4*>(table + (int64_t)id * row_bytes)[c];
+}
+int launch_disc_embed(const void* table, int op_dtype, int vocab, const int32_t* ids, int64_t n_tok, int E,
+                      void* out, hipStream_t st) {
+  prof::Scope prof_scope(prof::DISC_SMALL, st);
+  if (n_tok == 0) return 0;
+  const int row_bytes = E * dtype_size(op_dtype);
+  NMTGAN_REQUIRE(row_bytes % 16 == 0, "disc_embed: dim_word*esize must be a multiple of 16 bytes");
+  const int64_t n = n_tok * (row_bytes >> 4);
+  hipLaunchKernelGGL(disc_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const char*)table,
+                     vocab, ids, n_tok, row_bytes, (char*)out);
+  NMTGAN_CHECK_LAUNCH("disc_embed");
+  return 0;
+}
+
+template <typename OpT>
+__global__ void cast_kernel(const float* in, OpT* out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float v[4];
+  VecIO<float, 4>::load(in + i, v);
+  VecIO<OpT, 4>::store(out + i, v);
+}
+int launch_cast_rows(const float* in, void* out, int op_dtype, int64_t n, hipStream_t st) {
+  prof::Scope prof_scope(prof::DISC_SMALL, st);
+  if (n == 0) return 0;
+  NMTGAN_REQUIRE(n % 4 == 0, "cast: n must be a multiple of 4");
+  dim3 grid((unsigned)((n / 4 + 255) / 256)), block(256);
+  if (op_dtype == NMTGAN_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, grid, block, 0, st, in, (bf16_t*)out, n);
+  else hipLaunchKernelGGL(cast_kernel<float>, grid, block, 0, st, in, (float*)out, n);
+  NMTGAN_CHECK_LAUNCH("cast");
+  return 0;
+}
+
+// highway (cnn_discriminator.py:50-59, layer_size 1, bias 0): out = sig(t)*relu(o) + (1-sig(t))*H
+__global__ void highway_gate_kernel(const float* H, const float* o, const float* t, float* out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float h[4], ov[4], tv[4], r[4];
+  VecIO<float, 4>::load(H + i, h);
+  VecIO<float, 4>::load(o + i, ov);
+  VecIO<float, 4>::load(t + i, tv);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gate = 1.f / (1.f + expf(-tv[e]));
+    r[e] = gate * fmaxf(ov[e], 0.f) + (1.f - gate) * h[e];
+  }
+  VecIO<float, 4>::store(out + i, r);
+}
+int launch_highway_gate(const float* H, const float* o, const float* t, float* out, int64_t n, hipStream_t st) {
+  prof::Scope prof_scope(prof::DISC_SMALL, st);
+  if (n == 0) return 0;
+  NMTGAN_REQUIRE(n % 4 == 0, "highway_gate: n must be a multiple of 4");
+  hipLaunchKernelGGL(highway_gate_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, H, o, t, out, n);
+  NMTGAN_CHECK_LAUNCH("highway_gate");
+  return 0;
+}
+
+// scores = [feat_t | feat_s] . W + b; softmax over 2 classes (cnn_discriminator.py:504-508)
+__global__ __launch_bounds__(256) void disc_head_kernel(const float* feat_t, const float* feat_s,
+                                                        const int32_t* src_row, int M, int Fp, const float* head_w,
+                                                        const float* head_b, float* p_real, float* probs2) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const float* ft = feat_t + (int64_t)r * Fp;
+  const float* fs = feat_s + (int64_t)(src_row ? src_row[r] : r) * Fp;
+  float s0 = 0.f, s1 = 0.f;
+  for (int i = lane; i < Fp; i += 64) {
+    const float a = ft[i], b = fs[i];
+    s0 = fmaf(a, head_w[i], s0);
+    s0 = fmaf(b, head_w[Fp + i], s0);
+    s1 = fmaf(a, head_w[2 * Fp + i], s1);
+    s1 = fmaf(b, head_w[3 * Fp + i], s1);
+  }
+  s0 = wave_sum(s0) + head_b[0];
+  s1 = wave_sum(s1) + head_b[1];
+  if (lane == 0) {
+    const float mx = fmaxf(s0, s1);
+    const float e0 = expf(s0 - mx), e1 = expf(s1 - mx);
+    const float inv = 1.f / (e0 + e1);
+    if (p_real) p_real[r] = e1 * inv;
+    if (probs2) { probs2[2 * r] = e0 * inv; probs2[2 * r + 1] = e1 * inv; }
+  }
+}
+int launch_disc_head(const float* feat_t, const float* feat_s, const int32_t* src_row, int M, int Fp,
+                     const float* head_w, const float* head_b, float* p_real, float* probs2, hipStream_t st) {
+  prof::Scope prof_scope(prof::DISC_SMALL, st);
+  if (M == 0) return 0;
+  NMTGAN_REQUIRE(feat_t && feat_s && head_w && head_b && (p_real || probs2), "disc_head: null pointer");
+  hipLaunchKernelGGL(disc_head_kernel, dim3((M + 3) / 4), dim3(256), 0, st, feat_t, feat_s, src_row, M, Fp, head_w,
+                     head_b, p_real, probs2);
+  NMTGAN_CHECK_LAUNCH("disc_head");
+  return 0;
+}
+
+// ------------------------------------------------------------------ reward averaging (model.py:315-345)
+__global__ void reward_reduce_kernel(const float* p, const float* p_base, const int32_t* grp_first,
+                                     const float* mask, int B, int T, int rollnum, int use_bias, float bias_total,
+                                     float* rewards) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T) return;
+  const int b = i / T, t = i % T;
+  float q = 0.f;
+  const int first = (t < T - 1) ? grp_first[b * (T - 1) + t] : -1;
+  if (first >= 0) {
+    for (int r = 0; r < rollnum; ++r) q += p[first + r];     // rewards[g-1] += ypred, roll order (model.py:319)
+  } else {
+    const float pb = p_base[b];
+    for (int r = 0; r < rollnum; ++r) q += pb;               // same D input every roll (model.py:321-332; B.6)
+  }
+  if (use_bias) q -= bias_total;                             // model.py:340-342 (fp32 bias array)
+  rewards[i] = (q * mask[i]) / (float)rollnum;               // model.py:344-345
+}
+int launch_reward_reduce(const float* p, const float* p_base, const int32_t* grp_first, const float* mask, int B,
+                         int T, int rollnum, int use_bias, double bias_num, float* rewards, hipStream_t st) {
+  prof::Scope prof_scope(prof::DISC_SMALL, st);
+  NMTGAN_REQUIRE(B > 0 && T > 1 && rollnum > 0, "reward_reduce: bad shape");
+  NMTGAN_REQUIRE(p_base && grp_first && mask && rewards, "reward_reduce: null pointer");
+  hipLaunchKernelGGL(reward_reduce_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, p, p_base, grp_first, mask,
+                     B, T, rollnum, use_bias, (float)(bias_num * (double)rollnum), rewards);
+  NMTGAN_CHECK_LAUNCH("reward_reduce");
+  return 0;
+}
+
+}  // namespace nmtgan

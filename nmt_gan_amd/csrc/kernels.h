@@ -1,0 +1,29 @@
+// Internal launch functions (host side) of the gfx950 kernels; the extern "C" ABI in api.hip and the
+// pipelines in pipeline.hip call these.
+#pragma once
+#include "common.h"
+
+namespace nmtgan {
+
+int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st);
+int launch_embed(const nmtgan_embed_args* a, hipStream_t st);
+int launch_add_layernorm(const nmtgan_addln_args* a, hipStream_t st);
+int launch_attn_rows(const nmtgan_attn_args* a, hipStream_t st);
+int launch_sample_rows(const nmtgan_sample_args* a, hipStream_t st);
+
+// rollout token bookkeeping (model.py:242-243, 250-252)
+int launch_init_rollouts(const int32_t* y, const int32_t* row_b, const int32_t* row_g, int n_rows, int T,
+                         int32_t* Y, hipStream_t st);
+int launch_scatter_tokens(const int32_t* tok, const int32_t* row_g, int add, int n, int T, int32_t* Y,
+                          hipStream_t st);
+// discriminator small kernels
+int launch_disc_embed(const void* table, int op_dtype, int vocab, const int32_t* ids, int64_t n_tok, int E,
+                      void* out, hipStream_t st);
+int launch_cast_rows(const float* in, void* out, int op_dtype, int64_t n, hipStream_t st);
+int launch_highway_gate(const float* H, const float* o, const float* t, float* out, int64_t n, hipStream_t st);
+int launch_disc_head(const float* feat_t, const float* feat_s, const int32_t* src_row, int M, int Fp,
+                     const float* head_w, const float* head_b, float* p_real, float* probs2, hipStream_t st);
+int launch_reward_reduce(const float* p, const float* p_base, const int32_t* grp_first, const float* mask, int B,
+                         int T, int rollnum, int use_bias, double bias_num, float* rewards, hipStream_t st);
+
+}  // namespace nmtgan

@@ -1,0 +1,561 @@
+// Host-side pipelines of libnmtgan_hip.so: they only enqueue kernels on the caller's stream.
+//
+//   encode            model.py:486-543      once per batch (the reference re-runs it per sess.run)
+//   cross K/V         common_attention.py:383-388, once per sentence and decoder block
+//   prefill           model.py:545-618 over shift_right(y_sample): shared K/V + prefix logits
+//   rollout steps     model.py:224-245 restructured: lock-step over all live (b, r, g) rows,
+//                     one position per step, private step-major KV cache
+//   discriminator     cnn_discriminator.py:440-522, source tower once per sentence
+//   reward reduce     model.py:315-345
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace nmtgan {
+
+static inline char* at(const void* base, int64_t elems, int es) { return (char*)base + elems * es; }
+
+// out[s] = (A . Wt^T + b) with up to 3 column segments
+static int dense(int op, const void* A, int64_t lda, int M, int K, int N, const nmtgan_dense& w, int n_seg,
+                 int seg_width, void* const* outs, const int64_t* ldos, const int* out_f32, const float* scales,
+                 int relu, hipStream_t st) {
+  nmtgan_gemm_args a{};
+  a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
+  a.A = A; a.Wt = w.w; a.M = M; a.N = N; a.K = K; a.lda = lda; a.a_group = 0;
+  a.bias = w.b; a.relu = relu; a.n_seg = n_seg; a.seg_width = seg_width;
+  for (int s = 0; s < n_seg; ++s) {
+    a.out[s] = outs[s]; a.ldo[s] = ldos[s]; a.out_f32[s] = out_f32[s]; a.seg_scale[s] = scales ? scales[s] : 1.f;
+  }
+  return launch_gemm(&a, st);
+}
+static int dense1(int op, const void* A, int64_t lda, int M, int K, int N, const nmtgan_dense& w, void* out,
+                  int64_t ldo, int out_is_f32, float scale, int relu, hipStream_t st) {
+  void* outs[1] = {out};
+  int64_t ld[1] = {ldo};
+  int f[1] = {out_is_f32};
+  float sc[1] = {scale};
+  return dense(op, A, lda, M, K, N, w, 1, N, outs, ld, f, sc, relu, st);
+}
+
+static int add_ln(const nmtgan_generator* g, float* xf, const float* yf, const nmtgan_ln& ln, int M, void* xo,
+                  const uint8_t* zero_row, hipStream_t st) {
+  nmtgan_addln_args a{};
+  a.x = xf; a.y = yf; a.gamma = ln.g; a.beta = ln.b; a.M = M; a.d = g->d;
+  a.out_f32 = xf; a.out_op = xo; a.op_dtype = g->op_dtype; a.zero_row = zero_row;
+  return launch_add_layernorm(&a, st);
+}
+
+static int check_generator(const nmtgan_generator* g) {
+  NMTGAN_REQUIRE(g != nullptr, "generator: null");
+  NMTGAN_REQUIRE(g->op_dtype == NMTGAN_BF16 || g->op_dtype == NMTGAN_F32, "generator: bad op_dtype");
+  NMTGAN_REQUIRE(g->d > 0 && g->d % 64 == 0 && g->d <= 1024, "generator: hidden_units must be a multiple of 64, <= 1024");
+  NMTGAN_REQUIRE(g->heads > 0 && 64 % g->heads == 0 && g->d % g->heads == 0, "generator: num_heads must divide 64");
+  NMTGAN_REQUIRE(g->n_blocks > 0 && g->n_blocks <= NMTGAN_MAX_BLOCKS, "generator: bad num_blocks");
+  NMTGAN_REQUIRE(g->vocab_dst % 4 == 0, "generator: dst_vocab_size must be a multiple of 4 (pad the softmax table)");
+  NMTGAN_REQUIRE(g->emb_src && g->emb_dst && g->softmax_w && g->timing, "generator: null table");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ activations
+struct Act {
+  float* xf; void* xo; float* yf; float* q; void* ao; void* h;
+};
+static void carve_act(Arena& ar, int64_t rows, int d, int es, Act& a) {
+  a.xf = ar.get<float>(rows * d);
+  a.xo = ar.take(rows * d * es);
+  a.yf = ar.get<float>(rows * d);
+  a.q = ar.get<float>(rows * d);
+  a.ao = ar.take(rows * d * es);
+  a.h = ar.take(rows * 4 * d * es);
+}
+
+// ------------------------------------------------------------------------------------------ encoder
+static int encode(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_pad, int B, int Ls, Act& a,
+                  void* kbuf, void* vbuf, hipStream_t st) {
+  const int op = g->op_dtype, d = g->d, M = B * Ls;
+  const float qscale = 1.0f / sqrtf((float)(d / g->heads));
+  nmtgan_embed_args e{};
+  e.table = g->emb_src; e.timing = g->timing; e.vocab = g->vocab_src; e.max_pos = g->max_pos;
+  e.tok = x; e.tok_ld = 1; e.pos_mod = Ls; e.mult = g->emb_mult; e.M = M; e.d = d;
+  e.out_f32 = a.xf; e.out_op = a.xo; e.op_dtype = op;
+  NMTGAN_REQUIRE(Ls <= g->max_pos, "encode: source length %d exceeds timing table %d", Ls, g->max_pos);
+  NMTGAN_TRY(launch_embed(&e, st));
+  for (int l = 0; l < g->n_blocks; ++l) {
+    const nmtgan_enc_block& b = g->enc[l];
+    void* outs[3] = {a.q, kbuf, vbuf};
+    int64_t ld[3] = {d, d, d};
+    int f32[3] = {1, 0, 0};
+    float sc[3] = {qscale, 1.f, 1.f};
+    NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st));
+    nmtgan_attn_args t{};
+    t.q = a.q; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
+    t.k1 = kbuf; t.v1 = vbuf; t.len1 = Ls; t.rows_per_blk = Ls; t.causal = 0; t.mask1 = x_pad; t.out = a.ao;
+    NMTGAN_TRY(launch_attn_rows(&t, st));
+    NMTGAN_TRY(dense1(op, a.ao, d, M, d, d, b.o, a.yf, d, 1, 1.f, 0, st));
+    NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln0, M, a.xo, nullptr, st));
+    NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
+    NMTGAN_TRY(dense1(op, a.h, 4 * d, M, 4 * d, d, b.ffn2, a.yf, d, 1, 1.f, 0, st));
+    NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln1, M, a.xo, l == g->n_blocks - 1 ? x_pad : nullptr, st));   // model.py:542
+  }
+  return 0;
+}
+
+// cross-attention K/V of every decoder block from the encoder output (op dtype, [B*Ls][d])
+static int cross_kv(const nmtgan_generator* g, const void* enc_op, int M, void* crossK, void* crossV, hipStream_t st) {
+  const int op = g->op_dtype, d = g->d, es = dtype_size(op);
+  for (int l = 0; l < g->n_blocks; ++l) {
+    void* outs[2] = {at(crossK, (int64_t)l * M * d, es), at(crossV, (int64_t)l * M * d, es)};
+    int64_t ld[2] = {d, d};
+    int f32[2] = {0, 0};
+    float sc[2] = {1.f, 1.f};
+    NMTGAN_TRY(dense(op, enc_op, d, M, d, 2 * d, g->dec[l].ckv, 2, d, outs, ld, f32, sc, 0, st));
+  }
+  return 0;
+}
+
+// One decoder pass over M rows that are already embedded in a.xf/a.xo.  Self-attention keys:
+// shared segment (shK/shV, per-row block/count or the causal rows_per_blk form) + private segment.
+struct DecAttn {
+  // self attention
+  const void* shK; const void* shV; int len_sh; int64_t sh_layer_stride;      // elements per block layer
+  const int32_t* seg1_blk; const int32_t* seg1_cnt; int rows_per_blk; int causal;
+  void* prK; void* prV; int64_t pr_layer_stride; const int64_t* step_off; int n_steps2;
+  // where this pass writes its own K/V (element offset inside a layer)
+  void* wrK; void* wrV; int64_t wr_layer_stride; int64_t wr_off;
+  // cross attention
+  const void* crossK; const void* crossV; int Ls; int64_t cross_layer_stride;
+  const int32_t* cross_blk; int cross_rows_per_blk; const uint8_t* x_pad;
+  int step_mode;   // 1: rollout step (profile classes attn_self/attn_cross), 0: prefill
+};
+
+static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn& c, hipStream_t st) {
+  const int op = g->op_dtype, d = g->d, es = dtype_size(op);
+  const float qscale = 1.0f / sqrtf((float)(d / g->heads));
+  for (int l = 0; l < g->n_blocks; ++l) {
+    const nmtgan_dec_block& b = g->dec[l];
+    {
+      void* outs[3] = {a.q, at(c.wrK, l * c.wr_layer_stride + c.wr_off, es), at(c.wrV, l * c.wr_layer_stride + c.wr_off, es)};
+      int64_t ld[3] = {d, d, d};
+      int f32[3] = {1, 0, 0};
+      float sc[3] = {qscale, 1.f, 1.f};
+      NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st));
+    }
+    {
+      nmtgan_attn_args t{};
+      t.q = a.q; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
+      if (c.shK) {
+        t.k1 = at(c.shK, l * c.sh_layer_stride, es); t.v1 = at(c.shV, l * c.sh_layer_stride, es);
+        t.len1 = c.len_sh; t.seg1_blk = c.seg1_blk; t.seg1_cnt = c.seg1_cnt; t.rows_per_blk = c.rows_per_blk;
+        t.causal = c.causal;
+      }
+      if (c.n_steps2 > 0) {
+        t.k2 = at(c.prK, l * c.pr_layer_stride, es); t.v2 = at(c.prV, l * c.pr_layer_stride, es);
+        t.step_off = c.step_off; t.n_steps2 = c.n_steps2;
+      }
+      t.out = a.ao;
+      prof::Hint ph(c.step_mode ? prof::ATTN_SELF : prof::ATTN_PREFILL);
+      NMTGAN_TRY(launch_attn_rows(&t, st));
+    }
+    NMTGAN_TRY(dense1(op, a.ao, d, M, d, d, b.o, a.yf, d, 1, 1.f, 0, st));
+    NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln0, M, a.xo, nullptr, st));
+    NMTGAN_TRY(dense1(op, a.xo, d, M, d, d, b.cq, a.q, d, 1, qscale, 0, st));
+    {
+      nmtgan_attn_args t{};
+      t.q = a.q; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
+      t.k1 = at(c.crossK, l * c.cross_layer_stride, es); t.v1 = at(c.crossV, l * c.cross_layer_stride, es);
+      t.len1 = c.Ls; t.seg1_blk = c.cross_blk; t.rows_per_blk = c.cross_rows_per_blk; t.causal = 0;
+      t.mask1 = c.x_pad; t.out = a.ao;
+      prof::Hint ph(c.step_mode ? prof::ATTN_CROSS : prof::ATTN_PREFILL);
+      NMTGAN_TRY(launch_attn_rows(&t, st));
+    }
+    NMTGAN_TRY(dense1(op, a.ao, d, M, d, d, b.co, a.yf, d, 1, 1.f, 0, st));
+    NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln1, M, a.xo, nullptr, st));
+    {
+      prof::Hint ph(prof::GEMM_FFN);
+      NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
+      NMTGAN_TRY(dense1(op, a.h, 4 * d, M, 4 * d, d, b.ffn2, a.yf, d, 1, 1.f, 0, st));
+    }
+    NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln2, M, a.xo, nullptr, st));
+  }
+  return 0;
+}
+
+static int logits_gemm(const nmtgan_generator* g, const void* x_op, int M, float* logits, hipStream_t st) {
+  nmtgan_dense w{g->softmax_w, nullptr};
+  prof::Hint ph(prof::GEMM_LOGITS);
+  return dense1(g->op_dtype, x_op, g->d, M, g->d, g->vocab_dst, w, logits, g->vocab_dst, 1, 1.f, 0, st);
+}
+
+// teacher-forced decoder over dec_in[B][T]; writes shared K/V and leaves the final states in a.xo
+static int prefill(const nmtgan_generator* g, const int32_t* dec_in, const uint8_t* x_pad, int B, int Ls, int T,
+                   Act& a, void* shK, void* shV, const void* crossK, const void* crossV, hipStream_t st) {
+  const int d = g->d, M = B * T;
+  NMTGAN_REQUIRE(T <= g->max_pos, "prefill: max_len %d exceeds timing table %d", T, g->max_pos);
+  nmtgan_embed_args e{};
+  e.table = g->emb_dst; e.timing = g->timing; e.vocab = g->vocab_dst; e.max_pos = g->max_pos;
+  e.tok = dec_in; e.tok_ld = 1; e.pos_mod = T; e.mult = 2.0f * g->emb_mult;      // model.py:565 (quirk B.2)
+  e.M = M; e.d = d; e.out_f32 = a.xf; e.out_op = a.xo; e.op_dtype = g->op_dtype;
+  NMTGAN_TRY(launch_embed(&e, st));
+  DecAttn c{};
+  c.shK = shK; c.shV = shV; c.len_sh = T; c.sh_layer_stride = (int64_t)M * d; c.rows_per_blk = T; c.causal = 1;
+  c.wrK = shK; c.wrV = shV; c.wr_layer_stride = (int64_t)M * d; c.wr_off = 0;
+  c.crossK = crossK; c.crossV = crossV; c.Ls = Ls; c.cross_layer_stride = (int64_t)B * Ls * d;
+  c.cross_rows_per_blk = T; c.x_pad = x_pad;
+  return decoder_pass(g, M, a, c, st);
+}
+
+// ------------------------------------------------------------------------------------------ discriminator
+static int check_disc(const nmtgan_discriminator* d) {
+  NMTGAN_REQUIRE(d != nullptr, "discriminator: null");
+  NMTGAN_REQUIRE(d->op_dtype == NMTGAN_BF16 || d->op_dtype == NMTGAN_F32, "discriminator: bad op_dtype");
+  NMTGAN_REQUIRE(d->n_widths > 0 && d->n_widths <= NMTGAN_MAX_WIDTHS, "discriminator: bad n_widths");
+  NMTGAN_REQUIRE(d->Fp % 64 == 0 && d->Fp >= d->F && d->F > 0, "discriminator: Fp must be F rounded up to 64");
+  NMTGAN_REQUIRE((d->dim_word * dtype_size(d->op_dtype)) % 16 == 0, "discriminator: dim_word misaligned");
+  int f = 0;
+  for (int i = 0; i < d->n_widths; ++i) {
+    NMTGAN_REQUIRE(d->widths[i] >= 1 && d->widths[i] <= d->max_len, "discriminator: filter width %d > max_len", d->widths[i]);
+    f += d->n_filters[i];
+  }
+  NMTGAN_REQUIRE(f == d->F, "discriminator: sum(num_filters) != F");
+  return 0;
+}
+
+struct DiscBufs { void* e; float* pooled; void* pooled_op; float* ho; float* ht; };
+static void carve_disc(Arena& ar, const nmtgan_discriminator* d, int chunk, DiscBufs& b) {
+  const int es = dtype_size(d->op_dtype);
+  b.e = ar.take((int64_t)chunk * d->max_len * d->dim_word * es);
+  b.pooled = ar.get<float>((int64_t)chunk * d->Fp);
+  b.pooled_op = ar.take((int64_t)chunk * d->Fp * es);
+  b.ho = ar.get<float>((int64_t)chunk * d->Fp);
+  b.ht = ar.get<float>((int64_t)chunk * d->Fp);
+}
+
+// highway features of `rows` sentences ids[rows][T] -> feat[rows][Fp]
+static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* ids,
+                               int rows, float* feat, DiscBufs& b, hipStream_t st) {
+  const int T = d->max_len, E = d->dim_word, Fp = d->Fp, op = d->op_dtype;
+  NMTGAN_TRY(launch_disc_embed(tw.emb, op, &tw == &d->src ? d->vocab_s : d->vocab, ids, (int64_t)rows * T, E, b.e, st));
+  if (hipMemsetAsync(b.pooled, 0, (size_t)rows * Fp * sizeof(float), st) != hipSuccess)
+    NMTGAN_FAIL(-3, "disc: memset failed");
+  int col = 0;
+  for (int i = 0; i < d->n_widths; ++i) {
+    const int w = d->widths[i], P = T - w + 1;
+    nmtgan_gemm_args a{};
+    a.op_dtype = op; a.epilogue = NMTGAN_EPI_CONVMAX;
+    a.A = b.e; a.Wt = tw.conv_w[i]; a.M = rows * P; a.N = d->n_filters[i]; a.K = w * E;
+    a.lda = E; a.a_group = P; a.a_group_stride = (int64_t)T * E;
+    a.scale = tw.conv_scale[i]; a.shift = tw.conv_shift[i]; a.pooled = b.pooled + col; a.ld_pool = Fp;
+    prof::Hint ph(prof::GEMM_CONV);
+    NMTGAN_TRY(launch_gemm(&a, st));
+    col += d->n_filters[i];
+  }
+  NMTGAN_TRY(launch_cast_rows(b.pooled, b.pooled_op, op, (int64_t)rows * Fp, st));
+  nmtgan_dense wo{tw.hw_out, nullptr}, wt{tw.hw_tr, nullptr};
+  {
+    prof::Hint ph(prof::GEMM_HIGHWAY);
+    NMTGAN_TRY(dense1(op, b.pooled_op, Fp, rows, Fp, Fp, wo, b.ho, Fp, 1, 1.f, 0, st));
+    NMTGAN_TRY(dense1(op, b.pooled_op, Fp, rows, Fp, Fp, wt, b.ht, Fp, 1, 1.f, 0, st));
+  }
+  return launch_highway_gate(b.pooled, b.ho, b.ht, feat, (int64_t)rows * Fp, st);
+}
+
+int disc_workspace(const nmtgan_discriminator* d, int chunk, size_t* bytes) {
+  NMTGAN_TRY(check_disc(d));
+  NMTGAN_REQUIRE(chunk > 0, "disc: chunk_rows must be positive");
+  Arena ar(nullptr, 0);
+  DiscBufs b;
+  carve_disc(ar, d, chunk, b);
+  *bytes = align_up(ar.off, 256);
+  return 0;
+}
+
+int disc_features(const nmtgan_discriminator* d, int source, const int32_t* ids, int M, float* feat, int chunk,
+                  void* ws, size_t ws_bytes, hipStream_t st) {
+  NMTGAN_TRY(check_disc(d));
+  NMTGAN_REQUIRE(chunk > 0 && M >= 0 && ids && feat, "disc_features: bad arguments");
+  Arena ar(ws, ws_bytes);
+  DiscBufs b;
+  carve_disc(ar, d, chunk, b);
+  NMTGAN_REQUIRE(ws != nullptr && !ar.overflow, "disc_features: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+  const nmtgan_disc_tower& tw = source ? d->src : d->tgt;
+  for (int r0 = 0; r0 < M; r0 += chunk) {
+    const int rows = M - r0 < chunk ? M - r0 : chunk;
+    NMTGAN_TRY(disc_features_chunk(d, tw, ids + (int64_t)r0 * d->max_len, rows, feat + (int64_t)r0 * d->Fp, b, st));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ rollout reward
+struct RewardBufs {
+  Act act;
+  void *kbuf, *vbuf, *crossK, *crossV, *shK, *shV, *prK, *prV;
+  float* logits; float* prefix_logits;
+  int32_t* Y; int32_t* tok_cur;
+  float *feat_s, *feat_t, *p_rows, *p_base;
+  DiscBufs disc;
+  int64_t act_rows, logits_rows, pr_rows;
+  int disc_chunk;
+};
+
+static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discriminator* d,
+                        const nmtgan_reward_plan* p, RewardBufs& b) {
+  const int es = dtype_size(g->op_dtype), dm = g->d, N = g->n_blocks;
+  const int64_t enc_rows = (int64_t)p->B * p->Ls, pre_rows = (int64_t)p->B * p->T;
+  int64_t act_rows = enc_rows > pre_rows ? enc_rows : pre_rows;
+  if (p->n_steps >= 1 && p->live[1] > act_rows) act_rows = p->live[1];
+  b.act_rows = act_rows;
+  carve_act(ar, act_rows, dm, es, b.act);
+  b.kbuf = ar.take(enc_rows * dm * es);
+  b.vbuf = ar.take(enc_rows * dm * es);
+  b.crossK = ar.take(N * enc_rows * dm * es);
+  b.crossV = ar.take(N * enc_rows * dm * es);
+  b.shK = ar.take(N * pre_rows * dm * es);
+  b.shV = ar.take(N * pre_rows * dm * es);
+  b.pr_rows = p->n_steps >= 1 ? p->step_off_host[p->n_steps] : 0;
+  b.prK = ar.take((size_t)N * b.pr_rows * dm * es);
+  b.prV = ar.take((size_t)N * b.pr_rows * dm * es);
+  int64_t lrows = p->logits_chunk_rows > 0 ? p->logits_chunk_rows : 4096;
+  if (p->n_steps >= 1 && p->live[1] < lrows) lrows = p->live[1];
+  if (lrows < 1) lrows = 1;
+  b.logits_rows = lrows;
+  b.logits = ar.get<float>(lrows * g->vocab_dst);
+  b.prefix_logits = p->prefix_logits ? p->prefix_logits : ar.get<float>(pre_rows * g->vocab_dst);
+  b.Y = p->rollouts ? p->rollouts : ar.get<int32_t>((int64_t)(p->n_rows > 0 ? p->n_rows : 1) * p->T);
+  b.tok_cur = ar.get<int32_t>(p->n_rows > 0 ? p->n_rows : 1);
+  b.disc_chunk = p->disc_chunk_rows > 0 ? p->disc_chunk_rows : 4096;
+  const int64_t most = p->n_rows > p->B ? p->n_rows : p->B;
+  if (b.disc_chunk > most) b.disc_chunk = (int)most;
+  b.feat_s = ar.get<float>((int64_t)p->B * d->Fp);
+  b.feat_t = ar.get<float>((int64_t)b.disc_chunk * d->Fp);
+  b.p_rows = p->p_rows ? p->p_rows : ar.get<float>(p->n_rows > 0 ? p->n_rows : 1);
+  b.p_base = p->p_base ? p->p_base : ar.get<float>(p->B);
+  carve_disc(ar, d, b.disc_chunk, b.disc);
+  return 0;
+}
+
+static int check_plan(const nmtgan_generator* g, const nmtgan_discriminator* d, const nmtgan_reward_plan* p) {
+  NMTGAN_TRY(check_generator(g));
+  NMTGAN_TRY(check_disc(d));
+  NMTGAN_REQUIRE(p != nullptr, "plan: null");
+  NMTGAN_REQUIRE(g->op_dtype == d->op_dtype, "generator and discriminator must be packed in the same op dtype");
+  NMTGAN_REQUIRE(p->B > 0 && p->Ls > 0 && p->T > 1 && p->rollnum > 0, "plan: bad B/Ls/T/rollnum");
+  NMTGAN_REQUIRE(p->T == d->max_len, "plan: max_len %d != discriminator max_len %d", p->T, d->max_len);
+  NMTGAN_REQUIRE(p->Ls <= g->max_pos && p->T <= g->max_pos, "plan: length exceeds timing table");
+  NMTGAN_REQUIRE(p->n_rows >= 0 && p->n_rows % p->rollnum == 0, "plan: n_rows must be a multiple of rollnum");
+  NMTGAN_REQUIRE(p->n_steps >= 0 && p->n_steps <= (p->T > 2 ? p->T - 2 : 0), "plan: n_steps must be in [0, T-2]");
+  NMTGAN_REQUIRE(p->live && p->step_off_host, "plan: null host tables");
+  NMTGAN_REQUIRE(p->live[0] == p->n_rows, "plan: live[0] != n_rows");
+  int64_t cum = 0;
+  NMTGAN_REQUIRE(p->step_off_host[0] == 0, "plan: step_off[0] must be 0");
+  for (int s = 1; s <= p->n_steps; ++s) {
+    NMTGAN_REQUIRE(p->live[s] > 0 && p->live[s] <= p->live[s - 1], "plan: live[] must be positive and non-increasing");
+    cum += p->live[s];
+    NMTGAN_REQUIRE(p->step_off_host[s] == cum, "plan: step_off[%d] inconsistent with live[]", s);
+  }
+  return 0;
+}
+
+int reward_workspace(const nmtgan_generator* g, const nmtgan_discriminator* d, const nmtgan_reward_plan* p,
+                     size_t* bytes) {
+  NMTGAN_TRY(check_plan(g, d, p));
+  Arena ar(nullptr, 0);
+  RewardBufs b;
+  NMTGAN_TRY(carve_reward(ar, g, d, p, b));
+  *bytes = align_up(ar.off, 256);
+  return 0;
+}
+
+int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, const nmtgan_reward_plan* p, void* ws,
+                   size_t ws_bytes, hipStream_t st) {
+  NMTGAN_TRY(check_plan(g, d, p));
+  NMTGAN_REQUIRE(p->x && p->x_pad && p->x_pad_to_T && p->y && p->dec_in && p->mask && p->grp_first && p->rewards,
+                 "plan: null input");
+  NMTGAN_REQUIRE(p->n_rows == 0 || (p->row_b && p->row_g && p->row_gp1 && p->row_lrow && p->row_uoff && p->uniforms),
+                 "plan: null row tables");
+  NMTGAN_REQUIRE(p->n_steps == 0 || p->step_off, "plan: null device step_off");
+  Arena ar(ws, ws_bytes);
+  RewardBufs b;
+  NMTGAN_TRY(carve_reward(ar, g, d, p, b));
+  NMTGAN_REQUIRE(ws != nullptr && !ar.overflow, "rollout_reward: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+  const int B = p->B, Ls = p->Ls, T = p->T, dm = g->d, V = g->vocab_dst, op = g->op_dtype;
+
+  // 1. encoder once, cross K/V once per block (the reference re-encodes on every sess.run)
+  NMTGAN_TRY(encode(g, p->x, p->x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
+  NMTGAN_TRY(cross_kv(g, b.act.xo, B * Ls, b.crossK, b.crossV, st));
+  // 2. teacher-forced pass over y_sample: shared K/V of positions 0..T-1 and the prefix logits
+  NMTGAN_TRY(prefill(g, p->dec_in, p->x_pad, B, Ls, T, b.act, b.shK, b.shV, b.crossK, b.crossV, st));
+  NMTGAN_TRY(logits_gemm(g, b.act.xo, B * T, b.prefix_logits, st));
+  // 3. rollouts
+  if (p->n_rows > 0) {
+    NMTGAN_TRY(launch_init_rollouts(p->y, p->row_b, p->row_g, p->n_rows, T, b.Y, st));
+    // first sampled token of row (b,r,g): position g, logits shared by all rolls of (b,g)
+    nmtgan_sample_args s{};
+    s.logits = b.prefix_logits; s.ld = V; s.V = V; s.M = p->n_rows; s.row_map = p->row_lrow;
+    s.u = p->uniforms; s.u_off = p->row_uoff; s.u_add = 0; s.out = b.tok_cur;
+    NMTGAN_TRY(launch_sample_rows(&s, st));
+    NMTGAN_TRY(launch_scatter_tokens(b.tok_cur, p->row_g, 0, p->n_rows, T, b.Y, st));
+    for (int step = 1; step <= p->n_steps; ++step) {
+      const int M = p->live[step];
+      nmtgan_embed_args e{};
+      e.table = g->emb_dst; e.timing = g->timing; e.vocab = V; e.max_pos = g->max_pos;
+      e.tok = b.Y; e.tok_ld = T; e.tok_col = p->row_g; e.tok_col_add = step - 1;     // input token y_{g+s-1}
+      e.pos = p->row_g; e.pos_add = step;                                            // position g+s
+      e.mult = 2.0f * g->emb_mult; e.M = M; e.d = dm; e.out_f32 = b.act.xf; e.out_op = b.act.xo; e.op_dtype = op;
+      NMTGAN_TRY(launch_embed(&e, st));
+      DecAttn c{};
+      c.shK = b.shK; c.shV = b.shV; c.len_sh = T; c.sh_layer_stride = (int64_t)B * T * dm;
+      c.seg1_blk = p->row_b; c.seg1_cnt = p->row_gp1;
+      c.prK = b.prK; c.prV = b.prV; c.pr_layer_stride = b.pr_rows * dm; c.step_off = p->step_off; c.n_steps2 = step;
+      c.wrK = b.prK; c.wrV = b.prV; c.wr_layer_stride = b.pr_rows * dm; c.wr_off = p->step_off_host[step - 1] * dm;
+      c.crossK = b.crossK; c.crossV = b.crossV; c.Ls = Ls; c.cross_layer_stride = (int64_t)B * Ls * dm;
+      c.cross_blk = p->row_b; c.x_pad = p->x_pad; c.step_mode = 1;
+      NMTGAN_TRY(decoder_pass(g, M, b.act, c, st));
+      for (int r0 = 0; r0 < M; r0 += (int)b.logits_rows) {
+        const int rows = M - r0 < b.logits_rows ? M - r0 : (int)b.logits_rows;
+        NMTGAN_TRY(logits_gemm(g, at(b.act.xo, (int64_t)r0 * dm, dtype_size(op)), rows, b.logits, st));
+        nmtgan_sample_args q{};
+        q.logits = b.logits; q.ld = V; q.V = V; q.M = rows;
+        q.u = p->uniforms; q.u_off = p->row_uoff + r0; q.u_add = step; q.out = b.tok_cur + r0;
+        NMTGAN_TRY(launch_sample_rows(&q, st));
+      }
+      NMTGAN_TRY(launch_scatter_tokens(b.tok_cur, p->row_g, step, M, T, b.Y, st));
+    }
+  }
+  // 4. discriminator: source tower once per sentence, target tower per rollout + once for y_sample
+  for (int r0 = 0; r0 < B; r0 += b.disc_chunk) {
+    const int rows = B - r0 < b.disc_chunk ? B - r0 : b.disc_chunk;
+    NMTGAN_TRY(disc_features_chunk(d, d->src, p->x_pad_to_T + (int64_t)r0 * T, rows, b.feat_s + (int64_t)r0 * d->Fp,
+                                   b.disc, st));
+  }
+  for (int r0 = 0; r0 < B; r0 += b.disc_chunk) {
+    const int rows = B - r0 < b.disc_chunk ? B - r0 : b.disc_chunk;
+    NMTGAN_TRY(disc_features_chunk(d, d->tgt, p->y + (int64_t)r0 * T, rows, b.feat_t, b.disc, st));
+    NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s + (int64_t)r0 * d->Fp, nullptr, rows, d->Fp, d->head_w, d->head_b,
+                                b.p_base + r0, nullptr, st));
+  }
+  for (int r0 = 0; r0 < p->n_rows; r0 += b.disc_chunk) {
+    const int rows = p->n_rows - r0 < b.disc_chunk ? p->n_rows - r0 : b.disc_chunk;
+    NMTGAN_TRY(disc_features_chunk(d, d->tgt, b.Y + (int64_t)r0 * T, rows, b.feat_t, b.disc, st));
+    NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s, p->row_b + r0, rows, d->Fp, d->head_w, d->head_b, b.p_rows + r0,
+                                nullptr, st));
+  }
+  // 5. per-prefix averaging
+  return launch_reward_reduce(b.p_rows, b.p_base, p->grp_first, p->mask, B, T, p->rollnum, p->use_bias, p->bias_num,
+                              p->rewards, st);
+}
+
+// ------------------------------------------------------------------------------------------ teacher-forced logits
+struct TfBufs { Act act; void *kbuf, *vbuf, *crossK, *crossV, *shK, *shV; };
+static void carve_tf(Arena& ar, const nmtgan_generator* g, int B, int Ls, int T, TfBufs& b) {
+  const int es = dtype_size(g->op_dtype), dm = g->d, N = g->n_blocks;
+  const int64_t enc_rows = (int64_t)B * Ls, pre_rows = (int64_t)B * T;
+  carve_act(ar, enc_rows > pre_rows ? enc_rows : pre_rows, dm, es, b.act);
+  b.kbuf = ar.take(enc_rows * dm * es);
+  b.vbuf = ar.take(enc_rows * dm * es);
+  b.crossK = ar.take(N * enc_rows * dm * es);
+  b.crossV = ar.take(N * enc_rows * dm * es);
+  b.shK = ar.take(N * pre_rows * dm * es);
+  b.shV = ar.take(N * pre_rows * dm * es);
+}
+int teacher_forced_workspace(const nmtgan_generator* g, int B, int Ls, int T, size_t* bytes) {
+  NMTGAN_TRY(check_generator(g));
+  NMTGAN_REQUIRE(B > 0 && Ls > 0 && T > 0, "teacher_forced: bad shape");
+  Arena ar(nullptr, 0);
+  TfBufs b;
+  carve_tf(ar, g, B, Ls, T, b);
+  *bytes = align_up(ar.off, 256);
+  return 0;
+}
+int teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_pad, const int32_t* dec_in,
+                          int B, int Ls, int T, float* logits, void* ws, size_t ws_bytes, hipStream_t st) {
+  NMTGAN_TRY(check_generator(g));
+  NMTGAN_REQUIRE(B > 0 && Ls > 0 && T > 0 && x && x_pad && dec_in && logits, "teacher_forced: bad arguments");
+  Arena ar(ws, ws_bytes);
+  TfBufs b;
+  carve_tf(ar, g, B, Ls, T, b);
+  NMTGAN_REQUIRE(ws != nullptr && !ar.overflow, "teacher_forced: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+  NMTGAN_TRY(encode(g, x, x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
+  NMTGAN_TRY(cross_kv(g, b.act.xo, B * Ls, b.crossK, b.crossV, st));
+  NMTGAN_TRY(prefill(g, dec_in, x_pad, B, Ls, T, b.act, b.shK, b.shV, b.crossK, b.crossV, st));
+  return logits_gemm(g, b.act.xo, B * T, logits, st);
+}
+
+// ------------------------------------------------------------------------------------------ greedy generation
+__global__ void fill_greedy_tables(int64_t* step_off, int n_steps, int B, int32_t* bos, int32_t* zeros, int32_t* blk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_steps) step_off[i] = (int64_t)i * B;
+  if (i < B) { zeros[i] = 0; blk[i] = i; }
+  if (i == 0) bos[0] = 2;                                       // <S> (model.py:764-766)
+}
+struct GreedyBufs {
+  Act act; void *kbuf, *vbuf, *crossK, *crossV, *prK, *prV; float* logits;
+  int64_t* step_off; int32_t *bos, *zeros, *blk, *tok_cur;
+};
+static void carve_greedy(Arena& ar, const nmtgan_generator* g, int B, int Ls, int T, GreedyBufs& b) {
+  const int es = dtype_size(g->op_dtype), dm = g->d, N = g->n_blocks;
+  const int64_t enc_rows = (int64_t)B * Ls;
+  carve_act(ar, enc_rows > B ? enc_rows : B, dm, es, b.act);
+  b.kbuf = ar.take(enc_rows * dm * es);
+  b.vbuf = ar.take(enc_rows * dm * es);
+  b.crossK = ar.take(N * enc_rows * dm * es);
+  b.crossV = ar.take(N * enc_rows * dm * es);
+  b.prK = ar.take((size_t)N * T * B * dm * es);
+  b.prV = ar.take((size_t)N * T * B * dm * es);
+  b.logits = ar.get<float>((int64_t)B * g->vocab_dst);
+  b.step_off = ar.get<int64_t>(T);
+  b.bos = ar.get<int32_t>(4);
+  b.zeros = ar.get<int32_t>(B);
+  b.blk = ar.get<int32_t>(B);
+  b.tok_cur = ar.get<int32_t>(B);
+}
+int generate_workspace(const nmtgan_generator* g, int B, int Ls, int T, size_t* bytes) {
+  NMTGAN_TRY(check_generator(g));
+  NMTGAN_REQUIRE(B > 0 && Ls > 0 && T > 0, "generate: bad shape");
+  Arena ar(nullptr, 0);
+  GreedyBufs b;
+  carve_greedy(ar, g, B, Ls, T, b);
+  *bytes = align_up(ar.off, 256);
+  return 0;
+}
+int generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_pad, int B, int Ls, int T,
+                    int32_t* y, void* ws, size_t ws_bytes, hipStream_t st) {
+  NMTGAN_TRY(check_generator(g));
+  NMTGAN_REQUIRE(B > 0 && Ls > 0 && T > 0 && x && x_pad && y, "generate: bad arguments");
+  NMTGAN_REQUIRE(T <= g->max_pos && Ls <= g->max_pos, "generate: length exceeds timing table");
+  Arena ar(ws, ws_bytes);
+  GreedyBufs b;
+  carve_greedy(ar, g, B, Ls, T, b);
+  NMTGAN_REQUIRE(ws != nullptr && !ar.overflow, "generate: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+  const int dm = g->d, V = g->vocab_dst, op = g->op_dtype;
+  NMTGAN_TRY(encode(g, x, x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
+  NMTGAN_TRY(cross_kv(g, b.act.xo, B * Ls, b.crossK, b.crossV, st));
+  const int nfill = T > B ? T : B;
+  hipLaunchKernelGGL(fill_greedy_tables, dim3((nfill + 255) / 256), dim3(256), 0, st, b.step_off, T, B, b.bos, b.zeros,
+                     b.blk);
+  NMTGAN_CHECK_LAUNCH("fill_greedy_tables");
+  if (hipMemsetAsync(y, 0, (size_t)B * T * sizeof(int32_t), st) != hipSuccess) NMTGAN_FAIL(-3, "generate: memset failed");
+  for (int i = 0; i < T; ++i) {
+    nmtgan_embed_args e{};
+    e.table = g->emb_dst; e.timing = g->timing; e.vocab = V; e.max_pos = g->max_pos;
+    if (i == 0) { e.tok = b.bos; e.tok_ld = 0; }
+    else { e.tok = y + (i - 1); e.tok_ld = T; }
+    e.pos_mod = 0; e.pos_add = i;
+    e.mult = 2.0f * g->emb_mult; e.M = B; e.d = dm; e.out_f32 = b.act.xf; e.out_op = b.act.xo; e.op_dtype = op;
+    NMTGAN_TRY(launch_embed(&e, st));
+    DecAttn c{};
+    c.prK = b.prK; c.prV = b.prV; c.pr_layer_stride = (int64_t)T * B * dm; c.step_off = b.step_off; c.n_steps2 = i + 1;
+    c.wrK = b.prK; c.wrV = b.prV; c.wr_layer_stride = (int64_t)T * B * dm; c.wr_off = (int64_t)i * B * dm;
+    c.crossK = b.crossK; c.crossV = b.crossV; c.Ls = Ls; c.cross_layer_stride = (int64_t)B * Ls * dm;
+    c.cross_blk = b.blk; c.x_pad = x_pad; c.step_mode = 1;
+    NMTGAN_TRY(decoder_pass(g, B, b.act, c, st));
+    NMTGAN_TRY(logits_gemm(g, b.act.xo, B, b.logits, st));
+    nmtgan_sample_args q{};
+    q.logits = b.logits; q.ld = V; q.V = V; q.M = B; q.greedy = 1; q.out = b.tok_cur;
+    NMTGAN_TRY(launch_sample_rows(&q, st));
+    NMTGAN_TRY(launch_scatter_tokens(b.tok_cur, b.zeros, i, B, T, y, st));
+  }
+  return 0;
+}
+
+}  // namespace nmtgan

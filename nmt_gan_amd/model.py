@@ -1,0 +1,382 @@
+"""Model facade: the generator surface gan_train.py / generate_samples.py call in the reference
+(model.py:18, 203-288, 291-346, 425-435), backed by libnmtgan_hip.so on one MI355X per process.
+
+In scope: get_reward (the hot path), generate_step / generate_and_save (greedy
+sampler, row f-1).  Training entry points raise NotImplementedError.
+
+Differences from the reference that a caller can see:
+  * numpy in / numpy out is unchanged; `uniforms=` / `seed=` are keyword-only extensions that
+    replace TF's unseeded Philox stream (model.py:239) with injected uniforms u[R, T-1, B, T].
+  * residual dropout, which the reference leaves ON during rollouts, is
+    neutralised: the path is deterministic given the uniforms.
+  * with torch.distributed initialised (one process per GPU, RCCL), get_reward shards the sentences
+    across ranks with the reference's split_tensor boundaries and all-gathers the reward rows.
+"""
+from __future__ import annotations
+
+import codecs
+import ctypes as C
+import logging
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr
+from .share_function import (build_rollout_plan, deal_generated_samples, shift_right, split_bounds,
+                             timing_signal)
+
+INT_TYPE = np.int32
+FLOAT_TYPE = np.float32
+
+
+def _cfg_get(cfg, path, default=None):
+    cur = cfg
+    for k in path.split("."):
+        if cur is None:
+            return default
+        cur = cur.get(k) if isinstance(cur, dict) else getattr(cur, k, None)
+    return default if cur is None else cur
+
+
+class Model(object):
+    def __init__(self, config, graph=None, sess=None, precision="bf16", device="cuda:0", max_pos=256):
+        self.graph = graph
+        self.sess = sess
+        self.config = config
+        self._logger = logging.getLogger('model')
+        self.precision = precision
+        self.device = torch.device(device)
+        if precision == "bf16":
+            self._tdtype, self._op = torch.bfloat16, _lib.NMTGAN_BF16
+        elif precision == "fp32":
+            self._tdtype, self._op = torch.float32, _lib.NMTGAN_F32
+        else:
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.hidden_units = int(_cfg_get(config, "hidden_units"))
+        self.num_blocks = int(_cfg_get(config, "num_blocks"))
+        self.num_heads = int(_cfg_get(config, "num_heads"))
+        self.src_vocab_size = int(_cfg_get(config, "src_vocab_size"))
+        self.dst_vocab_size = int(_cfg_get(config, "dst_vocab_size"))
+        self.scale_embedding = bool(_cfg_get(config, "scale_embedding", True))
+        self.shared_embedding = bool(_cfg_get(config, "train.shared_embedding", False))
+        if self.num_blocks > _lib.MAX_BLOCKS:
+            raise ValueError("num_blocks > %d" % _lib.MAX_BLOCKS)
+        self.max_pos = int(max_pos)
+        self.max_len = None
+        self.is_training = False
+        self._keep, self._c = [], None
+        self._ws = None
+        self.logits_chunk_rows = 4096
+        self.disc_chunk_rows = 4096
+        self.last_details = None
+
+    # ------------------------------------------------------------------ graph-building surface
+    def build_train_model(self):
+        """Reference: model.py:67-106 (MLE training graph; also flips is_training, which makes the
+        reference apply dropout during rollouts - quirk B.1, neutralised here)."""
+        self.is_training = True
+        rate = float(_cfg_get(self.config, "residual_dropout_rate", 0.0) or 0.0)
+        if rate != 0.0:
+            self._logger.warning("residual_dropout_rate=%g ignored on the rollout path (deterministic rollouts)", rate)
+
+    def build_generate(self, max_len, generate_devices=None, optimizer='rmsprop'):
+        """Reference: model.py:108-201.  Only the greedy sampler half is in scope."""
+        self.max_len = int(max_len)
+
+    def build_rollout_generate(self, max_len, roll_generate_devices=None):
+        """Reference: model.py:203-266."""
+        self.max_len = int(max_len)
+
+    def init_and_restore(self, modelFile=None, weights: Optional[Dict[str, np.ndarray]] = None):
+        """Reference: model.py:425-435 (tf.train.Saver restore).  Accepts a dict of TF-named arrays
+         or a .npz written with those names."""
+        if weights is None:
+            if modelFile is None:
+                raise ValueError("init_and_restore: pass weights= or a .npz modelFile")
+            with np.load(modelFile, allow_pickle=False) as z:
+                weights = {k: z[k] for k in z.files}
+        self.load_weights(weights)
+
+    def load_weights(self, W: Dict[str, np.ndarray]):
+        dev, td = self.device, self._tdtype
+        d = self.hidden_units
+        keep = []
+
+        def dv(a, dtype):
+            t = torch.as_tensor(np.ascontiguousarray(a)).to(device=dev, dtype=dtype).contiguous()
+            keep.append(t)
+            return t
+
+        def kernel2d(name):
+            k = np.asarray(W[name + "/kernel"], np.float32)
+            return k.reshape(k.shape[-2], k.shape[-1])            # conv kernels are [1,1,din,dout]
+
+        def dense(cd, name):
+            cd.w = ptr(dv(kernel2d(name).T, td))                  # Wt[N][K]
+            cd.b = ptr(dv(np.asarray(W[name + "/bias"], np.float32), torch.float32))
+
+        def lnorm(cl, name):
+            cl.g = ptr(dv(np.asarray(W[name + "/layer_norm_scale"], np.float32), torch.float32))
+            cl.b = ptr(dv(np.asarray(W[name + "/layer_norm_bias"], np.float32), torch.float32))
+
+        c = _lib.Generator()
+        c.op_dtype = self._op
+        c.d, c.heads, c.n_blocks = d, self.num_heads, self.num_blocks
+        c.vocab_src, c.vocab_dst = self.src_vocab_size, self.dst_vocab_size
+        c.emb_mult = float(np.float32(d ** 0.5)) if self.scale_embedding else 1.0     # model.py:494, 553
+        if self.shared_embedding:
+            shared = dv(np.asarray(W["embedding/shared/kernel"], np.float32), torch.float32)
+            c.emb_src = c.emb_dst = ptr(shared)
+            c.softmax_w = ptr(dv(np.asarray(W["embedding/shared/kernel"], np.float32), td))
+        else:
+            c.emb_src = ptr(dv(np.asarray(W["embedding/src_embedding/kernel"], np.float32), torch.float32))
+            c.emb_dst = ptr(dv(np.asarray(W["embedding/dst_embedding/kernel"], np.float32), torch.float32))
+            c.softmax_w = ptr(dv(np.asarray(W["embedding/softmax/kernel"], np.float32), td))
+        c.timing = ptr(dv(timing_signal(self.max_pos, d), torch.float32))
+        c.max_pos = self.max_pos
+        for i in range(self.num_blocks):
+            p = "encoder/block_%d/" % i
+            e = c.enc[i]
+            dense(e.qkv, p + "encoder_self_attention/qkv_transform_single")
+            dense(e.o, p + "encoder_self_attention/output_transform_single")
+            dense(e.ffn1, p + "conv_hidden_relu/conv1_single")
+            dense(e.ffn2, p + "conv_hidden_relu/conv2_single")
+            lnorm(e.ln0, p + "layer_norm")
+            lnorm(e.ln1, p + "layer_norm_1")
+            p = "decoder/block_%d/" % i
+            b = c.dec[i]
+            dense(b.qkv, p + "decoder_self_attention/qkv_transform_single")
+            dense(b.o, p + "decoder_self_attention/output_transform_single")
+            dense(b.cq, p + "decoder_vanilla_attention/q_transform_single")
+            dense(b.ckv, p + "decoder_vanilla_attention/kv_transform_single")
+            dense(b.co, p + "decoder_vanilla_attention/output_transform_single")
+            dense(b.ffn1, p + "conv_hidden_relu/conv1_single")
+            dense(b.ffn2, p + "conv_hidden_relu/conv2_single")
+            lnorm(b.ln0, p + "layer_norm")
+            lnorm(b.ln1, p + "layer_norm_1")
+            lnorm(b.ln2, p + "layer_norm_2")
+        self._keep, self._c = keep, c
+        return self
+
+    @property
+    def c_struct(self):
+        if self._c is None:
+            raise RuntimeError("Model: init_and_restore()/load_weights() has not been called")
+        return self._c
+
+    def _workspace(self, need):
+        if need == 0:
+            raise _lib.NmtGanError("workspace query failed: " + lib.nmtgan_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _dev_i32(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+
+    # ------------------------------------------------------------------ greedy generation (row f-1)
+    def generate_step(self, sentence_x):
+        """Reference: model.py:268-271 -> greedy while_loop model.py:140-176.  int32 [B, max_len]."""
+        if self.max_len is None:
+            raise RuntimeError("call build_generate(max_len, ...) first")
+        x = np.ascontiguousarray(np.asarray(sentence_x), dtype=np.int32)
+        B, Ls = x.shape
+        T = self.max_len
+        xd = self._dev_i32(x)
+        pad = (xd == 0).to(torch.uint8).contiguous()
+        y = torch.empty((B, T), dtype=torch.int32, device=self.device)
+        g = self.c_struct
+        ws = self._workspace(lib.nmtgan_generate_workspace_bytes(C.byref(g), B, Ls, T))
+        check(lib.nmtgan_generate_greedy(C.byref(g), ptr(xd), ptr(pad), B, Ls, T, ptr(y), ptr(ws), ws.numel(),
+                                         _lib.stream_ptr()), "nmtgan_generate_greedy")
+        torch.cuda.synchronize(self.device)
+        return y.cpu().numpy()
+
+    def generate_and_save(self, data_util, infile, generate_batch, outfile):
+        """Reference: model.py:278-288."""
+        with codecs.open(outfile, 'w', 'utf-8') as out:
+            for batch in data_util.get_test_batches(infile, generate_batch):
+                out_generate = self.generate_step(batch)
+                dealed, _ = deal_generated_samples(out_generate, data_util.dst2idx)
+                for y_str in data_util.indices_to_words_del_pad(dealed, 'dst'):
+                    out.write(y_str + '\n')
+
+    def generate_step_and_update(self, sentence_x, sentence_y, reward):
+        raise NotImplementedError("policy-gradient update is outside the rollout-reward path (SURVEY section 8f-3)")
+
+    # ------------------------------------------------------------------ parity hook
+    def teacher_forced_logits(self, x, y):
+        """Logits [B, T, V] of decoder(shift_right(y)) given x (model.py:486-618, 804-820)."""
+        x = np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+        y = np.ascontiguousarray(np.asarray(y), dtype=np.int32)
+        B, Ls = x.shape
+        T = y.shape[1]
+        xd = self._dev_i32(x)
+        pad = (xd == 0).to(torch.uint8).contiguous()
+        dec_in = self._dev_i32(shift_right(y))
+        out = torch.empty((B, T, self.dst_vocab_size), dtype=torch.float32, device=self.device)
+        g = self.c_struct
+        ws = self._workspace(lib.nmtgan_teacher_forced_workspace_bytes(C.byref(g), B, Ls, T))
+        check(lib.nmtgan_teacher_forced_logits(C.byref(g), ptr(xd), ptr(pad), ptr(dec_in), B, Ls, T, ptr(out),
+                                               ptr(ws), ws.numel(), _lib.stream_ptr()), "nmtgan_teacher_forced_logits")
+        torch.cuda.synchronize(self.device)
+        return out.cpu().numpy()
+
+    # ------------------------------------------------------------------ the hot path
+    def make_uniforms(self, rollnum, max_len, batch, seed):
+        """u[R, T-1, B, T] ~ U[0,1) fp32 from torch's Philox generator on the device."""
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(int(seed))
+        return torch.rand((rollnum, max_len - 1, batch, max_len), generator=gen, device=self.device,
+                          dtype=torch.float32)
+
+    def get_reward(self, x, x_to_maxlen, y_sample, y_sample_mask, rollnum, disc, max_len=50, bias_num=None,
+                   data_util=None, *, uniforms=None, seed=None, return_details=False, shard=True):
+        """Reference: Model.get_reward, model.py:291-346.  Returns float32 [B, max_len].
+
+        uniforms: optional [rollnum, max_len-1, B, max_len] array/tensor, u[r, g-1, b, t] is consumed
+        when rollout (r, give_num g) of sentence b samples position t >= g; else drawn from `seed`.
+        """
+        x = np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+        x_pad_T = np.ascontiguousarray(np.asarray(x_to_maxlen), dtype=np.int32)
+        y = np.ascontiguousarray(np.asarray(y_sample), dtype=np.int32)
+        mask = np.ascontiguousarray(np.asarray(y_sample_mask), dtype=np.float32)
+        B, Ls = x.shape
+        T = int(max_len)
+        if y.shape != (B, T) or mask.shape != (B, T) or x_pad_T.shape != (B, T):
+            raise ValueError("x_to_maxlen, y_sample and y_sample_mask must be [batch, max_len=%d]" % T)
+        if Ls > T:
+            raise ValueError("source longer than max_len (extend_sentence_to_maxlen would raise, quirk B.5)")
+        if disc.max_len != T:
+            raise ValueError("disc.max_len != max_len")
+        rollnum = int(rollnum)
+        if uniforms is None:
+            uniforms = self.make_uniforms(rollnum, T, B, 0 if seed is None else seed)
+        u = torch.as_tensor(uniforms)
+        if tuple(u.shape) != (rollnum, T - 1, B, T):
+            raise ValueError("uniforms must have shape [rollnum, max_len-1, batch, max_len]")
+        u = u.to(device=self.device, dtype=torch.float32).contiguous()
+
+        world, rank = 1, 0
+        if shard and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+        bounds = split_bounds(B, world)
+        b0, b1 = bounds[rank], bounds[rank + 1]
+        local = self._reward_local(x[b0:b1], x_pad_T[b0:b1], y[b0:b1], mask[b0:b1], rollnum, disc, T, bias_num, u,
+                                   b_offset=b0, B_global=B, return_details=return_details)
+        if world == 1:
+            out = local
+        else:
+            out = gather_rows(local, bounds, self.device)
+        torch.cuda.synchronize(self.device)
+        return out.cpu().numpy()
+
+    def _reward_local(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, b_offset, B_global, return_details):
+        if x.shape[0] == 0:
+            return torch.zeros((0, T), dtype=torch.float32, device=self.device)
+        prep = self.prepare_reward(x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, b_offset=b_offset,
+                                   B_global=B_global, return_details=return_details)
+        rewards = prep.launch()
+        if return_details:
+            torch.cuda.synchronize(self.device)
+            self.last_details = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in prep.details.items()}
+        return rewards
+
+    def prepare_reward(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, b_offset=0, B_global=None,
+                       return_details=False):
+        """Host half of get_reward: build the rollout plan, upload ids/tables, size the workspace.
+        Returns a PreparedReward whose launch() only enqueues device work (inputs resident in HBM)."""
+        dev = self.device
+        x = np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+        B, Ls = x.shape
+        plan = build_rollout_plan(mask, rollnum, b_offset=b_offset, B_global=B if B_global is None else B_global)
+        xd = self._dev_i32(x)
+        t = {
+            "x": xd, "x_pad": (xd == 0).to(torch.uint8).contiguous(), "x_pad_T": self._dev_i32(x_pad_T),
+            "y": self._dev_i32(y), "dec_in": self._dev_i32(shift_right(y)),
+            "mask": torch.as_tensor(np.ascontiguousarray(mask, dtype=np.float32)).to(dev),
+            "row_b": self._dev_i32(plan.row_b), "row_g": self._dev_i32(plan.row_g),
+            "row_gp1": self._dev_i32(plan.row_g + 1), "row_lrow": self._dev_i32(plan.row_lrow),
+            "row_uoff": torch.as_tensor(plan.row_uoff).to(dev), "grp_first": self._dev_i32(plan.grp_first),
+            "step_off": torch.as_tensor(plan.step_off).to(dev),
+            "u": torch.as_tensor(u).to(device=dev, dtype=torch.float32).contiguous(),
+            "rewards": torch.zeros((B, T), dtype=torch.float32, device=dev),
+        }
+        live = np.ascontiguousarray(plan.live, dtype=np.int32)
+        step_off_h = np.ascontiguousarray(plan.step_off, dtype=np.int64)
+        p = _lib.RewardPlan()
+        p.B, p.Ls, p.T, p.rollnum = B, Ls, T, int(rollnum)
+        p.n_rows, p.n_steps = plan.n_rows, plan.n_steps
+        p.live = live.ctypes.data
+        p.step_off_host = step_off_h.ctypes.data
+        p.step_off = ptr(t["step_off"])
+        p.x, p.x_pad, p.x_pad_to_T = ptr(t["x"]), ptr(t["x_pad"]), ptr(t["x_pad_T"])
+        p.y, p.dec_in, p.mask = ptr(t["y"]), ptr(t["dec_in"]), ptr(t["mask"])
+        p.row_b, p.row_g, p.row_gp1 = ptr(t["row_b"]), ptr(t["row_g"]), ptr(t["row_gp1"])
+        p.row_lrow, p.row_uoff, p.grp_first = ptr(t["row_lrow"]), ptr(t["row_uoff"]), ptr(t["grp_first"])
+        p.uniforms = ptr(t["u"])
+        p.use_bias = 0 if bias_num is None else 1
+        p.bias_num = 0.0 if bias_num is None else float(bias_num)
+        p.logits_chunk_rows = self.logits_chunk_rows
+        p.disc_chunk_rows = self.disc_chunk_rows
+        p.rewards = ptr(t["rewards"])
+        details = None
+        if return_details:
+            details = {
+                "plan": plan,
+                "rollouts": torch.zeros((max(plan.n_rows, 1), T), dtype=torch.int32, device=dev),
+                "p_rows": torch.zeros(max(plan.n_rows, 1), dtype=torch.float32, device=dev),
+                "p_base": torch.zeros(B, dtype=torch.float32, device=dev),
+                "prefix_logits": torch.zeros((B, T, self.dst_vocab_size), dtype=torch.float32, device=dev),
+            }
+            p.rollouts, p.p_rows = ptr(details["rollouts"]), ptr(details["p_rows"])
+            p.p_base, p.prefix_logits = ptr(details["p_base"]), ptr(details["prefix_logits"])
+        g, dsc = self.c_struct, disc.c_struct
+        need = lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(dsc), C.byref(p))
+        ws = self._workspace(need)
+        return PreparedReward(self, disc, plan, p, t, (live, step_off_h), ws, details)
+
+    def get_reward_Obinforced(self, *a, **k):
+        raise NotImplementedError("get_reward_Obinforced is never called by the reference drivers (SURVEY section 2 #5)")
+
+
+class PreparedReward(object):
+    """One get_reward call with every input already resident in HBM; launch() enqueues the whole
+    path on the current stream (no allocation, no synchronisation) and returns the device tensor
+    [B, T] the rewards are written to."""
+
+    def __init__(self, model, disc, plan, cplan, tensors, host_tables, ws, details):
+        self.model, self.disc, self.plan, self.cplan = model, disc, plan, cplan
+        self.tensors, self.host_tables, self.ws, self.details = tensors, host_tables, ws, details
+
+    @property
+    def workspace_bytes(self):
+        return int(self.ws.numel())
+
+    def launch(self):
+        g, dsc = self.model.c_struct, self.disc.c_struct
+        check(lib.nmtgan_rollout_reward(C.byref(g), C.byref(dsc), C.byref(self.cplan), ptr(self.ws), self.ws.numel(),
+                                        _lib.stream_ptr()), "nmtgan_rollout_reward")
+        return self.tensors["rewards"]
+
+
+def gather_rows(local: torch.Tensor, bounds, device) -> torch.Tensor:
+    """All-gather of per-rank reward rows [B_i, T] -> [B, T] (the implicit tf.concat of the tower
+    outputs, model.py:261 / cnn_discriminator.py:558).  Shards may be uneven (split_tensor uses
+    float linspace boundaries), so rows are padded to the largest shard for the collective."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    sizes = [bounds[i + 1] - bounds[i] for i in range(world)]
+    mx = max(max(sizes), 1)
+    T = local.shape[1]
+    backend = dist.get_backend()
+    work_dev = device if backend == "nccl" else torch.device("cpu")
+    padded = torch.zeros((mx, T), dtype=torch.float32, device=work_dev)
+    padded[: local.shape[0]] = local.to(work_dev)
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    return torch.cat([parts[i][: sizes[i]] for i in range(world)], dim=0).to(device)

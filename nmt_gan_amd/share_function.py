@@ -1,0 +1,126 @@
+"""Host-side numpy helpers on the rollout-reward path (same names as the reference's
+share_function.py) plus the rollout plan builder used by Model.get_reward."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+PAD_ID, UNK_ID, BOS_ID, EOS_ID = 0, 1, 2, 3      # reference utils.py:39, 269, 287
+
+
+def deal_generated_samples(y_sample, dicts=None):
+    """Zero every position from the first </S> on; mask = 1 before it.
+    Mirrors share_function.py:269-289 (`dicts` is the dst word->id map; </S> defaults to id 3)."""
+    eos = EOS_ID if dicts is None else dicts.get("</S>", EOS_ID)
+    y_sample = np.asarray(y_sample)
+    n, L = y_sample.shape
+    hit = y_sample == eos
+    first = np.where(hit.any(axis=1), hit.argmax(axis=1), L)
+    keep = np.arange(L)[None, :] < first[:, None]
+    return np.where(keep, y_sample, 0).astype(np.int32), keep.astype(np.float32)
+
+
+def extend_sentence_to_maxlen(seqs, maxlen=50):
+    """Zero-pad every sentence to maxlen (share_function.py:240-245); like the reference it
+    raises if a sentence is longer than maxlen."""
+    x = np.zeros((len(seqs), maxlen), dtype=np.int32)
+    for i, s in enumerate(seqs):
+        s = np.asarray(s)
+        if len(s) > maxlen:
+            raise ValueError("sentence %d has length %d > maxlen %d" % (i, len(s), maxlen))
+        x[i, :len(s)] = s
+    return x
+
+
+def timing_signal(length, channels):
+    """Sinusoid table of add_timing_signal_1d (tensor2tensor/common_attention.py:55-67), evaluated
+    in fp32 like the TF graph: sines in the first half of the channels, cosines in the second."""
+    position = np.arange(length, dtype=np.float32)
+    nt = channels // 2
+    inc = np.float32(math.log(1.0e4)) / (np.float32(nt) - np.float32(1.0))
+    inv = np.exp(np.arange(nt, dtype=np.float32) * -inc).astype(np.float32)
+    scaled = position[:, None] * inv[None, :]
+    sig = np.concatenate([np.sin(scaled), np.cos(scaled)], axis=1).astype(np.float32)
+    if channels % 2:
+        sig = np.pad(sig, [[0, 0], [0, 1]])
+    return sig
+
+
+def shift_right(y, pad=BOS_ID):
+    """Decoder input [<S>, y_0 .. y_{T-2}] (model.py:764-766)."""
+    y = np.asarray(y)
+    return np.concatenate([np.full_like(y[:, :1], pad), y[:, :-1]], axis=1)
+
+
+def split_bounds(batch_size, n):
+    """Shard boundaries of split_tensor (model.py:742-753): int(linspace(0, B, n+1))."""
+    return [int(v) for v in np.linspace(0.0, float(batch_size), n + 1).astype(np.float32).astype(np.int32)]
+
+
+@dataclass
+class RolloutPlan:
+    """Row order of the lock-step rollout: one row per live (sentence b, roll r, prefix g), sorted by
+    remaining private steps (descending) so that the live rows of step s are the prefix [0, live[s])."""
+    B: int
+    T: int
+    rollnum: int
+    lens: np.ndarray          # [B] mask length of each sentence
+    row_b: np.ndarray         # [n_rows] int32 (local sentence index)
+    row_r: np.ndarray
+    row_g: np.ndarray
+    row_lrow: np.ndarray      # b*T + g
+    row_uoff: np.ndarray      # int64 offset of u[r, g-1, b_global, g]
+    grp_first: np.ndarray     # [B, T-1] int32 first row of (b, g) or -1
+    live: np.ndarray          # [n_steps+1] int32
+    step_off: np.ndarray      # [n_steps+1] int64
+
+    @property
+    def n_rows(self):
+        return int(self.row_b.shape[0])
+
+    @property
+    def n_steps(self):
+        return int(self.live.shape[0] - 1)
+
+
+def build_rollout_plan(y_sample_mask, rollnum, b_offset=0, B_global=None) -> RolloutPlan:
+    """Rows (b, r, g) for 1 <= g < len_b: for g >= len_b the masked rollout equals y_sample[b]
+    (model.py:307), so those are scored once through p_base.  Row (b, r, g) samples
+    positions g .. len_b-1: the first from the shared prefix logits, then len_b-1-g private steps.
+    Uniforms are addressed by GLOBAL sentence index so any sharding draws identical tokens."""
+    mask = np.asarray(y_sample_mask)
+    B, T = mask.shape
+    lens = (mask != 0).sum(axis=1).astype(np.int64)
+    if not np.array_equal(mask != 0, np.arange(T)[None, :] < lens[:, None]):
+        raise ValueError("y_sample_mask must be a prefix of ones per row (deal_generated_samples output)")
+    if B_global is None:
+        B_global = B
+    bs, gs = [], []
+    for b in range(B):
+        g = np.arange(1, int(lens[b]), dtype=np.int64)
+        bs.append(np.full(g.shape, b, np.int64))
+        gs.append(g)
+    bb = np.concatenate(bs) if bs else np.zeros(0, np.int64)
+    gg = np.concatenate(gs) if gs else np.zeros(0, np.int64)
+    steps = lens[bb] - 1 - gg
+    order = np.lexsort((gg, bb, -steps))                 # primary: steps desc, then b, then g
+    bb, gg, steps = bb[order], gg[order], steps[order]
+    n_grp = bb.shape[0]
+    row_b = np.repeat(bb, rollnum)
+    row_g = np.repeat(gg, rollnum)
+    row_r = np.tile(np.arange(rollnum, dtype=np.int64), n_grp)
+    row_steps = np.repeat(steps, rollnum)
+    grp_first = np.full((B, max(T - 1, 1)), -1, np.int32)
+    grp_first[bb, gg - 1] = (np.arange(n_grp) * rollnum).astype(np.int32)
+    n_steps = int(steps.max()) if n_grp else 0
+    live = np.array([(row_steps >= s).sum() for s in range(n_steps + 1)], dtype=np.int32)
+    live[0] = row_b.shape[0]
+    step_off = np.zeros(n_steps + 1, np.int64)
+    step_off[1:] = np.cumsum(live[1:].astype(np.int64))
+    row_uoff = ((row_r * (T - 1) + (row_g - 1)) * B_global + (row_b + b_offset)) * T + row_g
+    return RolloutPlan(B=B, T=T, rollnum=rollnum, lens=lens, row_b=row_b.astype(np.int32),
+                       row_r=row_r.astype(np.int32), row_g=row_g.astype(np.int32),
+                       row_lrow=(row_b * T + row_g).astype(np.int32), row_uoff=row_uoff.astype(np.int64),
+                       grp_first=grp_first, live=live, step_off=step_off)
