@@ -1,0 +1,153 @@
+"""CPU tests of the host side: reference-named helpers, the rollout plan, the C-ABI library
+(loads and exports every symbol include/nmtgan.h declares; no compute without a GPU), argument
+validation of the entry points, and the N>1 sharding/gather path under gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nmt_gan_amd import _lib
+    header = open(os.path.join(ROOT, "include", "nmtgan.h")).read()
+    declared = set(re.findall(r"\b(nmtgan_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 18
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libnmtgan_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.lib.nmtgan_version() == 1
+
+
+def test_ctypes_struct_sizes_match_header_layout():
+    """Guards the hand-mirrored ctypes structs: sizes follow from the C layout rules."""
+    from nmt_gan_amd import _lib
+    assert C.sizeof(_lib.Dense) == 16 and C.sizeof(_lib.Ln) == 16
+    assert C.sizeof(_lib.EncBlock) == 6 * 16 and C.sizeof(_lib.DecBlock) == 10 * 16
+    assert C.sizeof(_lib.Generator) == 7 * 4 + 4 + 4 * 8 + 8 + 16 * (96 + 160)   # 7 ints+pad, 4 ptrs, max_pos+pad
+    assert C.sizeof(_lib.DiscTower) == 8 + 3 * 32 * 8 + 16
+    assert C.sizeof(_lib.GemmArgs) % 8 == 0 and C.sizeof(_lib.RewardPlan) % 8 == 0
+
+
+def test_entry_points_validate_before_launch():
+    """Host-side argument checks fail with a message and never touch the GPU."""
+    from nmt_gan_amd import _lib
+    a = _lib.GemmArgs()
+    a.op_dtype, a.epilogue, a.M, a.N, a.K = 0, 0, 4, 4, 3          # K*2 bytes not a multiple of 16
+    a.A = a.Wt = 4096
+    a.lda = 8
+    rc = _lib.lib.nmtgan_gemm(C.byref(a), None)
+    assert rc != 0 and b"multiple of 16" in _lib.lib.nmtgan_last_error()
+    s = _lib.SampleArgs()
+    s.M, s.V, s.logits, s.out, s.u = 1, 30, 4096, 4096, 4096       # V % 4 != 0
+    s.ld = 32
+    assert _lib.lib.nmtgan_sample_rows(C.byref(s), None) != 0
+    t = _lib.AttnArgs()
+    t.M, t.d, t.heads = 2, 96, 4                                   # d % 64 != 0
+    assert _lib.lib.nmtgan_attn_rows(C.byref(t), None) != 0
+    with pytest.raises(_lib.NmtGanError):
+        _lib.check(-2, "x")
+
+
+def test_reference_named_helpers():
+    import nmt_gan_amd as N
+    y = np.array([[5, 6, 3, 7, 3], [4, 4, 4, 4, 4], [3, 9, 9, 9, 9]], np.int32)
+    yd, m = N.deal_generated_samples(y, {"</S>": 3})
+    assert np.array_equal(yd, [[5, 6, 0, 0, 0], [4, 4, 4, 4, 4], [0, 0, 0, 0, 0]])
+    assert np.array_equal(m, [[1, 1, 0, 0, 0], [1, 1, 1, 1, 1], [0, 0, 0, 0, 0]])
+    assert yd.dtype == np.int32 and m.dtype == np.float32
+    assert np.array_equal(N.extend_sentence_to_maxlen([[1, 2], [3]], 4), [[1, 2, 0, 0], [3, 0, 0, 0]])
+    with pytest.raises(ValueError):
+        N.extend_sentence_to_maxlen([[1, 2, 3]], 2)
+    # same table as the oracle's restatement of add_timing_signal_1d
+    from oracle import nmtgan_oracle as O
+    assert np.array_equal(N.timing_signal(50, 64), O.timing_signal(50, 64))
+    # split_tensor boundaries (model.py:751-753), uneven shards allowed
+    assert N.split_bounds(10, 4) == [0, 2, 5, 7, 10]
+    assert N.split_bounds(64, 8) == list(range(0, 65, 8))
+    cfg = N.AttrDict({"a": 1, "train": {"shared_embedding": False}})
+    assert cfg.a == 1 and cfg.train.shared_embedding is False
+
+
+def test_rollout_plan_invariants():
+    import nmt_gan_amd as N
+    rng = np.random.default_rng(0)
+    B, T, R = 7, 11, 3
+    lens = np.array([11, 0, 1, 2, 6, 11, 4])
+    mask = (np.arange(T)[None] < lens[:, None]).astype(np.float32)
+    p = N.build_rollout_plan(mask, R, b_offset=20, B_global=64)
+    # one row per (b, r, g) with 1 <= g < len_b
+    want = sum(max(int(l) - 1, 0) for l in lens) * R
+    assert p.n_rows == want == p.live[0]
+    steps = lens[p.row_b] - 1 - p.row_g
+    assert (np.diff(steps) <= 0).all()                              # sorted by remaining steps
+    for s in range(p.n_steps + 1):
+        assert p.live[s] == (steps >= s).sum()
+        assert (steps[:p.live[s]] >= s).all()                       # live rows are a prefix
+    assert p.n_steps == lens.max() - 2
+    assert np.array_equal(p.step_off, np.concatenate([[0], np.cumsum(p.live[1:])]))
+    # groups of R adjacent rows, r = 0..R-1 in order; grp_first addresses them
+    assert np.array_equal(p.row_r.reshape(-1, R), np.tile(np.arange(R), (p.n_rows // R, 1)))
+    for b in range(B):
+        for g in range(1, T):
+            f = p.grp_first[b, g - 1]
+            if g < lens[b]:
+                assert (p.row_b[f:f + R] == b).all() and (p.row_g[f:f + R] == g).all()
+            else:
+                assert f == -1
+    # uniforms are addressed by GLOBAL sentence id: u[r, g-1, b+20, g] of a [R, T-1, 64, T] tensor
+    u = np.arange(R * (T - 1) * 64 * T).reshape(R, T - 1, 64, T)
+    assert np.array_equal(u.reshape(-1)[p.row_uoff], u[p.row_r, p.row_g - 1, p.row_b + 20, p.row_g])
+    with pytest.raises(ValueError):
+        bad = mask.copy()
+        bad[0, 3] = 0
+        N.build_rollout_plan(bad, R)
+
+
+_GLOO_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from nmt_gan_amd.model import gather_rows
+from nmt_gan_amd.share_function import split_bounds, build_rollout_plan
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+B, T, R = 5, 6, 2                                  # uneven shards: [0,2,5]
+bounds = split_bounds(B, 2)
+assert bounds == [0, 2, 5]
+full = np.arange(B * T, dtype=np.float32).reshape(B, T)
+local = torch.from_numpy(full[bounds[rank]:bounds[rank + 1]].copy())
+out = gather_rows(local, bounds, torch.device("cpu"))
+assert out.shape == (B, T) and np.array_equal(out.numpy(), full), out
+# sharded plans draw the same uniforms as the unsharded one
+mask = np.ones((B, T), np.float32); mask[3, 4:] = 0
+whole = build_rollout_plan(mask, R)
+part = build_rollout_plan(mask[bounds[rank]:bounds[rank + 1]], R, b_offset=bounds[rank], B_global=B)
+key = lambda p, off: {(int(b) + off, int(r), int(g)): int(u) for b, r, g, u in zip(p.row_b, p.row_r, p.row_g, p.row_uoff)}
+kw, kp = key(whole, 0), key(part, bounds[rank])
+assert all(kw[k] == v for k, v in kp.items()) and len(kp) == part.n_rows
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo_sharding_and_gather(tmp_path):
+    """The N>1 path (sentence sharding with split_tensor bounds + all-gather of reward rows) under
+    gloo, world_size 2, on CPU; RCCL uses the same code with backend nccl."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
