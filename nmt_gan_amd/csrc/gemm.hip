@@ -1,18 +1,26 @@
 // MFMA GEMM for gfx950: C[M,N] = A[M,K] . Wt[N,K]^T with fused epilogues.
 //
 // Both operands are K-contiguous, so A and Wt tiles share one loader and one LDS image:
-// 128 rows x 128 BYTES per k-tile (64 bf16 or 32 fp32), 16-byte chunks XOR-swizzled by
-// (row>>1)&7 so the ds_read_b128 fragment reads of a 32-row MFMA operand are conflict-free
-// (bank = (addr/4)%64, 16-lane groups: cdna_hip_programming.md section 2).
-// Block = 256 threads = 4 waves (2x2), block tile 128x128, wave tile 64x64 = 2x2 MFMA 32x32 tiles.
+// rows of 128 BYTES per k-tile (64 bf16 or 32 fp32), 16-byte chunks XOR-swizzled by (row>>1)&7 so
+// the ds_read_b128 fragment reads of a 32-row MFMA operand are conflict-free (bank = (addr/4)%64,
+// 16-lane groups: cdna_hip_programming.md section 2).
+// Wave tile 64x64 = 2x2 MFMA 32x32 tiles:
 //   bf16: v_mfma_f32_32x32x16_bf16, one per (16-byte A chunk, 16-byte B chunk) pair
 //   fp32: v_mfma_f32_32x32x2_f32, four per chunk pair (exact fp32, the 1e-5 parity tier)
 // The k order inside a tile is whatever the chunk order gives; A and B use the same order, so the
 // sum is over the same k set (order differs from the reference's, as any GEMM's does).
-// Register-staged double buffering: global loads of tile t+1 are issued before the MFMAs of tile t
-// and written to the other LDS buffer after them; one barrier per k-tile.
+//
+// Two main loops:
+//   gemm_glds_kernel  (K*esize % 128 == 0, every production shape): tiles go HBM/L2 -> LDS directly
+//       with global_load_lds_dwordx4 (no staging registers, no ds_write).  One wave instruction
+//       writes 1 KiB = 8 rows linearly, so the swizzle is applied to the per-lane SOURCE address
+//       (guide rule 21).  Double-buffered, one barrier per k-tile; block tile BM x BN in {128,256}x128.
+//   gemm_kernel       (any K with K*esize % 16 == 0): register-staged 128x128 fallback that zero
+//       fills the k tail.
 // Tile order: XCD-aware remap (blocks b and b+8 share an XCD / L2) + grouped-M order inside it so
 // GROUP_M row panels of A stay L2-resident while the Wt tiles stream.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -20,10 +28,11 @@ namespace nmtgan {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-constexpr int BM = 128, BN = 128, BKB = 128;   // BKB: k-tile width in bytes
+constexpr int BKB = 128;                        // k-tile width in bytes
 constexpr int GROUP_M = 16;
-constexpr int TILE_BYTES = BM * BKB;            // 16 KiB per operand per buffer
 
 struct GemmParams {
   const char* A; const char* W;
@@ -32,9 +41,9 @@ struct GemmParams {
   int a_group; int64_t a_group_stride_b;
   int64_t ldw_b;            // bytes per Wt row (= K*esize)
   int kbytes;               // K * esize
-  int ntm, ntn;
+  int ntm, ntn, group_m;
   // linear epilogue
-  const float* bias; int relu; int n_seg; int seg_width;
+  const float* bias; int relu; int n_seg; int seg_width; int wide_ok;
   void* out[3]; int64_t ldo[3]; int out_f32[3]; float seg_scale[3];
   // convmax epilogue
   const float* scale; const float* shift; float* pooled; int64_t ld_pool;
@@ -54,106 +63,30 @@ __device__ __forceinline__ void mma_chunk<float>(const uint4& a, const uint4& b,
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
 }
 
-template <typename OpT, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 buffers][A 16K | B 16K]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // ---- tile index: bijective XCD remap, then grouped-M order
+// bijective XCD remap + grouped-M order -> (tile_m, tile_n)
+__device__ __forceinline__ void tile_index(const GemmParams& p, int& tm, int& tn) {
   const int nwg = p.ntm * p.ntn;
-  int idx;
-  {
-    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
+  const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int group_size = GROUP_M * p.ntn;
-  const int group_id = idx / group_size;
-  const int first_m = group_id * GROUP_M;
+  const int first_m = (idx / group_size) * GROUP_M;
   const int gsz = min(p.ntm - first_m, GROUP_M);
-  const int tm = first_m + (idx % group_size) % gsz;
-  const int tn = (idx % group_size) / gsz;
-  const int bm0 = tm * BM, bn0 = tn * BN;
+  tm = first_m + (idx % group_size) % gsz;
+  tn = (idx % group_size) / gsz;
+}
 
-  // ---- loader mapping: thread -> (row r0 + 32 i, chunk c)
-  const int lc = tid & 7, lr0 = tid >> 3;
-  const int lds_wr = lr0 * BKB + ((lc ^ ((lr0 >> 1) & 7)) << 4);
-  const char* a_ptr[4];
-  const char* w_ptr[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int r = min(bm0 + lr0 + 32 * i, p.M - 1);
-    int64_t off = (p.a_group > 0) ? (int64_t)(r / p.a_group) * p.a_group_stride_b + (int64_t)(r % p.a_group) * p.lda_b
-                                  : (int64_t)r * p.lda_b;
-    a_ptr[i] = p.A + off + lc * 16;
-    int n = min(bn0 + lr0 + 32 * i, p.N - 1);
-    w_ptr[i] = p.W + (int64_t)n * p.ldw_b + lc * 16;
-  }
-  const int nkt = (p.kbytes + BKB - 1) / BKB;
+__device__ __forceinline__ int64_t a_row_offset(const GemmParams& p, int r) {
+  return (p.a_group > 0) ? (int64_t)(r / p.a_group) * p.a_group_stride_b + (int64_t)(r % p.a_group) * p.lda_b
+                         : (int64_t)r * p.lda_b;
+}
 
-  uint4 sa[4], sb[4];
-  auto gload = [&](int kt) {
-    const int kb = kt * BKB + lc * 16;
-    const bool ok = kb < p.kbytes;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      sa[i] = ok ? *reinterpret_cast<const uint4*>(a_ptr[i] + (int64_t)kt * BKB) : make_uint4(0, 0, 0, 0);
-      sb[i] = ok ? *reinterpret_cast<const uint4*>(w_ptr[i] + (int64_t)kt * BKB) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto lstore = [&](int buf) {
-    unsigned char* base = smem + buf * 2 * TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(base + lds_wr + i * 32 * BKB) = sa[i];
-      *reinterpret_cast<uint4*>(base + TILE_BYTES + lds_wr + i * 32 * BKB) = sb[i];
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // fragment read addressing: row = lane&31 (+32 per MFMA tile), chunk = 2q + (lane>>5)
+// Epilogue of one wave's 64x64 tile.  32x32 C layout: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
+template <typename OpT, int EPI>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int lane) {
   const int fr = lane & 31, fh = lane >> 5;
-  const int fsw = (fr >> 1) & 7;
-  const int a_rd = (wm * 64 + fr) * BKB;
-  const int b_rd = TILE_BYTES + (wn * 64 + fr) * BKB;
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) gload(kt + 1);
-    const unsigned char* base = smem + cur * 2 * TILE_BYTES;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int pc = ((2 * q + fh) ^ fsw) << 4;
-      uint4 fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const uint4*>(base + a_rd + i * 32 * BKB + pc);
-        fb[i] = *reinterpret_cast<const uint4*>(base + b_rd + i * 32 * BKB + pc);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) mma_chunk<OpT>(fa[i], fb[j], acc[i][j]);
-    }
-    if (kt + 1 < nkt) lstore(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // ---- epilogue.  32x32 C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = bn0 + wn * 64 + j * 32 + fr;
+    const int n = n0 + j * 32 + fr;
     if (n >= p.N) continue;
     if constexpr (EPI == NMTGAN_EPI_LINEAR) {
       const float bias = p.bias ? p.bias[n] : 0.f;
@@ -168,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = bm0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
           if (m < p.M) {
             float v = (acc[i][j][e] + bias) * sc;
             if (p.relu) v = fmaxf(v, 0.f);
@@ -185,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = bm0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
           if (m < p.M) {
             const float v = fmaxf(acc[i][j][e] * sc + sh, 0.f);
             const int g = m / p.a_group;
@@ -206,18 +139,415 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   }
 }
 
+// one k-tile of MFMAs for a wave: A rows at a_rd, W rows at b_rd inside `base`
+template <typename OpT>
+__device__ __forceinline__ void compute_tile(const unsigned char* base, int a_rd, int b_rd, int fh, int fsw,
+                                             f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int pc = ((2 * q + fh) ^ fsw) << 4;
+    uint4 fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[i] = *reinterpret_cast<const uint4*>(base + a_rd + i * 32 * BKB + pc);
+      fb[i] = *reinterpret_cast<const uint4*>(base + b_rd + i * 32 * BKB + pc);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) mma_chunk<OpT>(fa[i], fb[j], acc[i][j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ glds kernel
+template <typename OpT, int EPI, int BM, int BN>
+__global__ __launch_bounds__(64 * (BM / 64) * (BN / 64)) void gemm_glds_kernel(GemmParams p) {
+  constexpr int NW = (BM / 64) * (BN / 64);
+  constexpr int WN = BN / 64;
+  constexpr int STAGE = (BM + BN) * BKB;          // bytes per LDS stage
+  constexpr int NINST = (BM + BN) / 8 / NW;       // glds instructions per wave per k-tile (8 rows each)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  int tm, tn;
+  tile_index(p, tm, tn);
+  const int bm0 = tm * BM, bn0 = tn * BN;
+
+  // staging: instruction j of this wave covers tile rows 8*(wave + j*NW) .. +7 of the stacked [A; W] image
+  const char* src[NINST];
+#pragma unroll
+  for (int j = 0; j < NINST; ++j) {
+    const int rho = 8 * (wave + j * NW) + (lane >> 3);
+    const int lc = (lane & 7) ^ ((rho >> 1) & 7);             // logical chunk this lane fetches
+    if (rho < BM) src[j] = p.A + a_row_offset(p, min(bm0 + rho, p.M - 1)) + lc * 16;
+    else src[j] = p.W + (int64_t)min(bn0 + rho - BM, p.N - 1) * p.ldw_b + lc * 16;
+  }
+  const int nkt = p.kbytes / BKB;
+  auto stage = [&](int buf, int kt) {
+#pragma unroll
+    for (int j = 0; j < NINST; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + (int64_t)kt * BKB),
+                                       (lds_ptr_t)(smem + buf * STAGE + (wave + j * NW) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int fsw = (fr >> 1) & 7;
+  const int a_rd = (wm * 64 + fr) * BKB;
+  const int b_rd = (BM + wn * 64 + fr) * BKB;
+
+  stage(0, 0);
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();                      // vmcnt(0) + barrier: tile kt landed, buffer cur^1 free
+    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    compute_tile<OpT>(smem + cur * STAGE, a_rd, b_rd, fh, fsw, acc);
+    cur ^= 1;
+  }
+  epilogue<OpT, EPI>(p, acc, bm0 + wm * 64, bn0 + wn * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------ pipelined kernel
+// Persistent 256x128 tile, 8 waves (2 per SIMD), 3 LDS stages of 48 KiB, one block per CU.
+// The (tile, k-tile) pairs of a block form ONE stream: loads run two k-tiles ahead of the MFMAs and
+// keep flowing across the epilogue into the next tile, so neither the per-tile prologue latency nor
+// the per-k-tile load latency is exposed.  Per iteration: counted s_waitcnt vmcnt (leaves the newest
+// stage in flight) -> raw s_barrier -> issue stage it+2 -> 16 MFMAs per wave from stage it.
+// The LDS-DMA loads are issued from inline asm on purpose: hipcc then keeps no vmcnt bookkeeping for
+// them (it would otherwise drain them with vmcnt(0) in front of every ds_read it cannot prove
+// disjoint), and the hand-placed counted waits below are the only ones (guide section 5.7).
+constexpr int PBM = 256, PBN = 128, PNW = 8, PSTAGE = (PBM + PBN) * BKB, PNINST = (PBM + PBN) / 8 / PNW;
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// LINEAR epilogue with 16-byte stores: each 16x32 accumulator chunk is transposed through a 2 KiB
+// per-wave LDS scratch so that a store instruction writes whole 128-byte (fp32) / 64-byte (bf16) row
+// segments: 16 (fp32) or 8 (bf16) store instructions per wave tile instead of 64 scalar ones.
+// Needs N % 64 == 0, segment widths % 64 == 0 and 16-byte aligned output rows (checked at launch).
+template <typename OpT>
+__device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int lane,
+                                              float* scr, bool f32_out, int seg, int nn0) {
+  const int fr = lane & 31, fh = lane >> 5;
+  const float sc = p.seg_scale[seg];
+  const int64_t ldo = p.ldo[seg];
+  char* outp = reinterpret_cast<char*>(p.out[seg]);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float bias = p.bias ? p.bias[n0 + j * 32 + fr] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+          float v = (acc[i][j][8 * c + e8] + bias) * sc;
+          if (p.relu) v = fmaxf(v, 0.f);
+          scr[((e8 & 3) + 8 * (e8 >> 2) + 4 * fh) * 32 + fr] = v;
+        }
+        const int mb = m0 + i * 32 + 16 * c;
+        if (f32_out) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int r = (lane >> 3) + 8 * t;
+            const float4 x = *reinterpret_cast<const float4*>(scr + r * 32 + 4 * (lane & 7));
+            if (mb + r < p.M)
+              *reinterpret_cast<float4*>(outp + ((int64_t)(mb + r) * ldo + nn0 + j * 32 + 4 * (lane & 7)) * 4) = x;
+          }
+        } else {
+          const int r = lane >> 2;
+          float x[8];
+          VecIO<float, 8>::load(scr + r * 32 + 8 * (lane & 3), x);
+          if (mb + r < p.M)
+            VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(outp) + (int64_t)(mb + r) * ldo + nn0 + j * 32 + 8 * (lane & 3), x);
+        }
+      }
+    }
+  }
+}
+
 template <typename OpT, int EPI>
-static int launch_gemm_t(const GemmParams& p, hipStream_t st) {
+__global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = p.ntm * p.ntn;
+  const int G = gridDim.x;
+  const int nkt = p.kbytes / BKB;
+  const int my_tiles = (nwg - (int)blockIdx.x + G - 1) / G;   // nkt >= 4 (launch guarantees it)
+
+  // tile of linear id L (XCD remap needs G % 8 == 0 or G == nwg; launch guarantees it)
+  auto tile_of = [&](int L, int& tm, int& tn) {
+    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+    const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    const int group_size = p.group_m * p.ntn;
+    const int first_m = (idx / group_size) * p.group_m;
+    const int gsz = min(p.ntm - first_m, p.group_m);
+    tm = first_m + (idx % group_size) % gsz;
+    tn = (idx % group_size) / gsz;
+  };
+
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
+  const char* src[PNINST];
+  auto set_src = [&](int L) {
+    int tm, tn;
+    tile_of(L, tm, tn);
+#pragma unroll
+    for (int j = 0; j < PNINST; ++j) {
+      const int rho = 8 * (wave + j * PNW) + (lane >> 3);
+      const int lc = (lane & 7) ^ ((rho >> 1) & 7);
+      if (rho < PBM) src[j] = p.A + a_row_offset(p, min(tm * PBM + rho, p.M - 1)) + lc * 16;
+      else src[j] = p.W + (int64_t)min(tn * PBN + rho - PBM, p.N - 1) * p.ldw_b + lc * 16;
+    }
+  };
+  int is_buf = 0;                                // LDS stage the next issue() fills
+  auto issue = [&]() {                           // one k-tile of the tile `src` points at; advances src
+#pragma unroll
+    for (int j = 0; j < PNINST; ++j) {
+      glds16(src[j], lds_base + is_buf * PSTAGE + (wave + j * PNW) * 1024);
+      src[j] += BKB;
+    }
+    is_buf = is_buf == 2 ? 0 : is_buf + 1;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int fsw = (fr >> 1) & 7;
+  const int a_rd = (wm * 64 + fr) * BKB;
+  const int b_rd = (PBM + wn * 64 + fr) * BKB;
+
+  float* scr = reinterpret_cast<float*>(smem + 3 * PSTAGE + wave * 2048);
+  // vmcnt counts loads AND stores in issue order.  `pend` = epilogue stores this wave issued after its
+  // newest LDS-DMA group; they are younger than the next two stages waited for, so those two waits
+  // let them stay in flight and a tile's output drains under the next tile's MFMAs.
+  int pend = 0, cbuf = 0;
+#define NMTGAN_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  auto step = [&](bool do_issue) {               // after the wait: barrier, prefetch, 16 MFMAs per wave
+    __builtin_amdgcn_s_barrier();
+    if (do_issue) issue();                       // fills the stage read one iteration ago (all waves are past it)
+    compute_tile<OpT>(smem + cbuf * PSTAGE, a_rd, b_rd, fh, fsw, acc);
+    cbuf = cbuf == 2 ? 0 : cbuf + 1;
+  };
+  set_src((int)blockIdx.x);
+  issue();
+  issue();
+  for (int t = 0; t < my_tiles; ++t) {
+    const bool has_next = t + 1 < my_tiles;
+    for (int kt = 0; kt < nkt - 2; ++kt) {       // k-tile kt landed, kt+1 in flight, prefetch kt+2
+      if (kt < 2 && pend == 16) NMTGAN_WAIT(PNINST + 16);
+      else if (kt < 2 && pend == 8) NMTGAN_WAIT(PNINST + 8);
+      else NMTGAN_WAIT(PNINST);
+      step(true);
+    }
+    pend = 0;
+    if (has_next) set_src((int)blockIdx.x + (t + 1) * G);
+    NMTGAN_WAIT(PNINST);                         // k-tile nkt-2: prefetch the next tile's k-tile 0
+    step(has_next);
+    if (has_next) NMTGAN_WAIT(PNINST);           // k-tile nkt-1: prefetch the next tile's k-tile 1
+    else NMTGAN_WAIT(0);
+    step(has_next);
+
+    int tm, tn;
+    tile_of((int)blockIdx.x + t * G, tm, tn);
+    const int m0 = tm * PBM + wm * 64, n0 = tn * PBN + wn * 64;
+    bool wide = false;
+    if constexpr (EPI == NMTGAN_EPI_LINEAR) wide = p.wide_ok && n0 < p.N;
+    if (wide) {
+      const int seg = (p.n_seg > 1) ? n0 / p.seg_width : 0;
+      const bool f32_out = p.out_f32[seg] != 0 || sizeof(OpT) == 4;
+      epilogue_wide<OpT>(p, acc, m0, n0, lane, scr, f32_out, seg, n0 - seg * p.seg_width);
+      if (tm * PBM + PBM <= p.M) pend = f32_out ? 16 : 8;      // every store instruction was issued
+    } else {
+      epilogue<OpT, EPI>(p, acc, m0, n0, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  }
+#undef NMTGAN_WAIT
+}
+
+template <typename OpT, int EPI>
+static int launch_pipe(GemmParams p, hipStream_t st) {
+  constexpr int smem = 3 * PSTAGE + PNW * 2048;  // 3 stages + per-wave epilogue scratch = 160 KiB
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<OpT, EPI>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<OpT, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      NMTGAN_FAIL(-3, "gemm: cannot raise dynamic LDS limit");
     attr_done = true;
   }
+  p.ntm = (p.M + PBM - 1) / PBM;
+  p.ntn = (p.N + PBN - 1) / PBN;
+  p.group_m = 2;                                 // tile order knob (L2 sharing of A panels vs Wt tiles); 1-4 measured best
+  if (const char* e = getenv("NMTGAN_GEMM_GM")) p.group_m = atoi(e);
+  if constexpr (EPI == NMTGAN_EPI_LINEAR) {
+    const int es = sizeof(OpT);
+    bool ok = p.N % 64 == 0 && (p.n_seg == 1 || p.seg_width % 64 == 0);
+    for (int s = 0; s < p.n_seg; ++s) {
+      const int oes = p.out_f32[s] ? 4 : es;
+      ok = ok && ((uintptr_t)p.out[s] % 16 == 0) && ((p.ldo[s] * oes) % 16 == 0);
+    }
+    p.wide_ok = ok ? 1 : 0;
+    if (const char* e = getenv("NMTGAN_GEMM_WIDE")) p.wide_ok = p.wide_ok && atoi(e);
+  }
   const int nwg = p.ntm * p.ntn;
-  hipLaunchKernelGGL((gemm_kernel<OpT, EPI>), dim3(nwg), dim3(256), 4 * TILE_BYTES, st, p);
+  const int grid = nwg < 256 ? nwg : 256;        // one block per CU; 256 % 8 == 0 keeps the XCD remap bijective
+  int smem_use = smem;
+  if (const char* e = getenv("NMTGAN_GEMM_SMEM")) smem_use = atoi(e);
+  hipLaunchKernelGGL((gemm_pipe_kernel<OpT, EPI>), dim3(grid), dim3(512), smem_use, st, p);
+  NMTGAN_CHECK_LAUNCH("gemm_pipe");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ generic kernel
+constexpr int GBM = 128, GBN = 128, GTILE = GBM * BKB;
+
+template <typename OpT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 buffers][A 16K | B 16K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  tile_index(p, tm, tn);
+  const int bm0 = tm * GBM, bn0 = tn * GBN;
+
+  const int lc = tid & 7, lr0 = tid >> 3;
+  const int lds_wr = lr0 * BKB + ((lc ^ ((lr0 >> 1) & 7)) << 4);
+  const char* a_ptr[4];
+  const char* w_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_ptr[i] = p.A + a_row_offset(p, min(bm0 + lr0 + 32 * i, p.M - 1)) + lc * 16;
+    w_ptr[i] = p.W + (int64_t)min(bn0 + lr0 + 32 * i, p.N - 1) * p.ldw_b + lc * 16;
+  }
+  const int nkt = (p.kbytes + BKB - 1) / BKB;
+
+  uint4 sa[4], sb[4];
+  auto gload = [&](int kt) {
+    const bool ok = kt * BKB + lc * 16 < p.kbytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sa[i] = ok ? *reinterpret_cast<const uint4*>(a_ptr[i] + (int64_t)kt * BKB) : make_uint4(0, 0, 0, 0);
+      sb[i] = ok ? *reinterpret_cast<const uint4*>(w_ptr[i] + (int64_t)kt * BKB) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* base = smem + buf * 2 * GTILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(base + lds_wr + i * 32 * BKB) = sa[i];
+      *reinterpret_cast<uint4*>(base + GTILE + lds_wr + i * 32 * BKB) = sb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int fsw = (fr >> 1) & 7;
+  const int a_rd = (wm * 64 + fr) * BKB;
+  const int b_rd = GTILE + (wn * 64 + fr) * BKB;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) gload(kt + 1);
+    compute_tile<OpT>(smem + cur * 2 * GTILE, a_rd, b_rd, fh, fsw, acc);
+    if (kt + 1 < nkt) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  epilogue<OpT, EPI>(p, acc, bm0 + wm * 64, bn0 + wn * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------ launch
+template <typename OpT, int EPI, int BM, int BN>
+static int launch_glds(GemmParams p, hipStream_t st) {
+  constexpr int smem = 2 * (BM + BN) * BKB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<OpT, EPI, BM, BN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      NMTGAN_FAIL(-3, "gemm: cannot raise dynamic LDS limit");
+    attr_done = true;
+  }
+  p.ntm = (p.M + BM - 1) / BM;
+  p.ntn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_glds_kernel<OpT, EPI, BM, BN>), dim3(p.ntm * p.ntn), dim3(64 * (BM / 64) * (BN / 64)), smem,
+                     st, p);
+  NMTGAN_CHECK_LAUNCH("gemm_glds");
+  return 0;
+}
+
+template <typename OpT, int EPI>
+static int launch_generic(GemmParams p, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<OpT, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GTILE) != hipSuccess)
+      NMTGAN_FAIL(-3, "gemm: cannot raise dynamic LDS limit");
+    attr_done = true;
+  }
+  p.ntm = (p.M + GBM - 1) / GBM;
+  p.ntn = (p.N + GBN - 1) / GBN;
+  hipLaunchKernelGGL((gemm_kernel<OpT, EPI>), dim3(p.ntm * p.ntn), dim3(256), 4 * GTILE, st, p);
   NMTGAN_CHECK_LAUNCH("gemm");
   return 0;
+}
+
+static int tile_override() {        // NMTGAN_GEMM_TILE=128|256|0(generic) for experiments; unset = heuristic
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("NMTGAN_GEMM_TILE");
+    v = e ? atoi(e) : -1;
+  }
+  return v;
+}
+
+template <typename OpT, int EPI>
+static int dispatch(const GemmParams& p, hipStream_t st) {
+  const int ov = tile_override();
+  if (p.kbytes % BKB != 0 || ov == 0) return launch_generic<OpT, EPI>(p, st);
+  // persistent pipelined 256x128 kernel when there are enough tiles to occupy the 256 CUs and the
+  // k-loop is long enough for its two-deep prefetch; else the simple double-buffered 128x128 kernel
+  const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 127) / 128);
+  const bool pipe_ok = p.kbytes / BKB >= 4;
+  if (pipe_ok && (ov == 3 || (ov < 0 && tiles256 >= 192))) return launch_pipe<OpT, EPI>(p, st);
+  if (ov == 256) return launch_glds<OpT, EPI, 256, 128>(p, st);
+  return launch_glds<OpT, EPI, 128, 128>(p, st);
 }
 
 int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st) {
@@ -240,8 +570,6 @@ int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st) {
   p.a_group_stride_b = a->a_group_stride * es;
   p.ldw_b = (int64_t)a->K * es;
   p.kbytes = a->K * es;
-  p.ntm = (a->M + BM - 1) / BM;
-  p.ntn = (a->N + BN - 1) / BN;
   if (a->epilogue == NMTGAN_EPI_LINEAR) {
     NMTGAN_REQUIRE(a->n_seg >= 1 && a->n_seg <= 3, "gemm: n_seg must be 1..3");
     NMTGAN_REQUIRE(a->n_seg == 1 || (a->seg_width > 0 && a->seg_width * a->n_seg >= a->N),
@@ -252,14 +580,14 @@ int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st) {
       p.seg_scale[s] = a->seg_scale[s];
       if (s < a->n_seg) NMTGAN_REQUIRE(a->out[s] != nullptr, "gemm: null output segment %d", s);
     }
-    return a->op_dtype == NMTGAN_BF16 ? launch_gemm_t<bf16_t, NMTGAN_EPI_LINEAR>(p, st)
-                                      : launch_gemm_t<float, NMTGAN_EPI_LINEAR>(p, st);
+    return a->op_dtype == NMTGAN_BF16 ? dispatch<bf16_t, NMTGAN_EPI_LINEAR>(p, st)
+                                      : dispatch<float, NMTGAN_EPI_LINEAR>(p, st);
   } else if (a->epilogue == NMTGAN_EPI_CONVMAX) {
     NMTGAN_REQUIRE(a->a_group > 0, "gemm: CONVMAX needs a_group (windows per sentence)");
     NMTGAN_REQUIRE(a->scale && a->shift && a->pooled, "gemm: CONVMAX needs scale/shift/pooled");
     p.scale = a->scale; p.shift = a->shift; p.pooled = a->pooled; p.ld_pool = a->ld_pool;
-    return a->op_dtype == NMTGAN_BF16 ? launch_gemm_t<bf16_t, NMTGAN_EPI_CONVMAX>(p, st)
-                                      : launch_gemm_t<float, NMTGAN_EPI_CONVMAX>(p, st);
+    return a->op_dtype == NMTGAN_BF16 ? dispatch<bf16_t, NMTGAN_EPI_CONVMAX>(p, st)
+                                      : dispatch<float, NMTGAN_EPI_CONVMAX>(p, st);
   }
   NMTGAN_FAIL(-2, "gemm: unknown epilogue %d", a->epilogue);
 }

@@ -1,0 +1,70 @@
+"""Micro-benchmark of nmtgan_gemm on the shapes of the C2 workload (HIP events, random data)."""
+import ctypes as C
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nmt_gan_amd import _lib as L
+
+dev = torch.device("cuda:0")
+SHAPES = [  # name, M, N, K, conv(P,T,E) or None, out_f32
+    ("qkv    M49152 N1536 K512", 49152, 1536, 512, None, 0),
+    ("proj   M49152 N512  K512", 49152, 512, 512, None, 1),
+    ("ffn1   M49152 N2048 K512", 49152, 2048, 512, None, 0),
+    ("ffn2   M49152 N512  K2048", 49152, 512, 2048, None, 1),
+    ("proj   M8192  N512  K512", 8192, 512, 512, None, 1),
+    ("proj   M1024  N512  K512", 1024, 512, 512, None, 1),
+    ("logits M4096  N32000 K512", 4096, 32000, 512, None, 1),
+    ("logits M16384 N32000 K512", 16384, 32000, 512, None, 1),
+    ("conv w1  S4096", 4096 * 50, 110, 512, (50, 50, 512), 1),
+    ("conv w13 S4096", 4096 * 38, 230, 13 * 512, (38, 50, 512), 1),
+    ("conv w25 S4096", 4096 * 26, 350, 25 * 512, (26, 50, 512), 1),
+    ("conv w37 S4096", 4096 * 14, 470, 37 * 512, (14, 50, 512), 1),
+    ("conv w49 S4096", 4096 * 2, 590, 49 * 512, (2, 50, 512), 1),
+    ("highway M4096 N4608 K4608", 4096, 4608, 4608, None, 1),
+]
+
+
+def run(name, M, N, K, conv, out_f32, iters=10):
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = L.GemmArgs()
+    a.op_dtype = L.NMTGAN_BF16
+    if conv:
+        P, T, E = conv
+        S = M // P
+        A = (torch.rand(S * T, E, device=dev, generator=g) * 2 - 1).bfloat16()
+        a.lda, a.a_group, a.a_group_stride = E, P, T * E
+    else:
+        A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).bfloat16()
+        a.lda = K
+    W = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).bfloat16()
+    a.A, a.Wt, a.M, a.N, a.K = A.data_ptr(), W.data_ptr(), M, N, K
+    keep = []
+    if conv:
+        a.epilogue = L.EPI_CONVMAX
+        sc = torch.ones(N, device=dev); sh = torch.zeros(N, device=dev)
+        pooled = torch.zeros(M // conv[0], 4608, device=dev)
+        a.scale, a.shift, a.pooled, a.ld_pool = sc.data_ptr(), sh.data_ptr(), pooled.data_ptr(), 4608
+        keep += [sc, sh, pooled]
+    else:
+        a.epilogue = L.EPI_LINEAR
+        bias = torch.zeros(N, device=dev)
+        out = torch.empty(M, N, device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        a.bias, a.n_seg, a.seg_width = bias.data_ptr(), 1, N
+        a.out[0], a.ldo[0], a.out_f32[0], a.seg_scale[0] = out.data_ptr(), N, out_f32, 1.0
+        keep += [bias, out]
+    st = L.stream_ptr()
+    for _ in range(2):
+        L.check(L.lib.nmtgan_gemm(C.byref(a), st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        L.check(L.lib.nmtgan_gemm(C.byref(a), st))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print("%-28s %8.3f ms  %7.1f TFLOP/s" % (name, ms, 2.0 * M * N * K / ms / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    for s in SHAPES:
+        run(*s)
