@@ -136,8 +136,32 @@ typedef struct {
   const uint8_t* mask1;
   const void* k2; const void* v2; const int64_t* step_off; int n_steps2;
   void* out;                 /* [M][d] kv_dtype */
+  /* optional running softmax state to continue from (written by nmtgan_attn_group in partial mode):
+   * un-normalised o_init[M][d], m_init[M][heads], l_init[M][heads]; all three or none */
+  const float* o_init; const float* m_init; const float* l_init;
 } nmtgan_attn_args;
 int nmtgan_attn_rows(const nmtgan_attn_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Group attention (bf16 only): the rows_per_group (<= 32) consecutive query rows of a group share one
+ * block of keys (the rollouts of one (sentence, prefix) pair share the teacher-forced prefix and the
+ * encoder memory), so K/V are loaded once per group and the products run on MFMA.  Same math as
+ * nmtgan_attn_rows segment 1 (common_attention.py:294-331).  k[nblk][len][d] row-major,
+ * vt[nblk][d][len_padded] TRANSPOSED values (nmtgan_transpose_v), len_padded a multiple of 32.
+ * row_blk / row_cnt are per-row arrays read at the first row of each group (row_cnt NULL -> len).
+ * Exactly one output mode: `out` (normalised, bf16 [M][d]) or the running state (o_part un-normalised
+ * fp32 [M][d], m_part/l_part [M][heads]) that nmtgan_attn_rows continues over private keys.
+ */
+typedef struct {
+  const float* q; int M, d, heads, rows_per_group;
+  const void* k; const void* vt; int len, len_padded;
+  const int32_t* row_blk; const int32_t* row_cnt; const uint8_t* mask;
+  void* out;
+  float* o_part; float* m_part; float* l_part;
+} nmtgan_attn_group_args;
+int nmtgan_attn_group(const nmtgan_attn_group_args* a, void* stream);
+/* v[nblk*len][d] bf16 -> vt[nblk][d][len_padded] bf16, zero padded */
+int nmtgan_transpose_v(const void* v, void* vt, int nblk, int len, int len_padded, int d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Categorical sampler with injected uniforms.  Replaces softmax -> log -> tf.multinomial(.,1)

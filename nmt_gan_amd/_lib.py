@@ -42,7 +42,15 @@ class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("M", i32), ("d", i32), ("heads", i32), ("kv_dtype", i32),
                 ("k1", vp), ("v1", vp), ("len1", i32),
                 ("seg1_blk", vp), ("seg1_cnt", vp), ("rows_per_blk", i32), ("causal", i32), ("mask1", vp),
-                ("k2", vp), ("v2", vp), ("step_off", vp), ("n_steps2", i32), ("out", vp)]
+                ("k2", vp), ("v2", vp), ("step_off", vp), ("n_steps2", i32), ("out", vp),
+                ("o_init", vp), ("m_init", vp), ("l_init", vp)]
+
+
+class AttnGroupArgs(C.Structure):
+    _fields_ = [("q", vp), ("M", i32), ("d", i32), ("heads", i32), ("rows_per_group", i32),
+                ("k", vp), ("vt", vp), ("len", i32), ("len_padded", i32),
+                ("row_blk", vp), ("row_cnt", vp), ("mask", vp), ("out", vp),
+                ("o_part", vp), ("m_part", vp), ("l_part", vp)]
 
 
 class SampleArgs(C.Structure):
@@ -104,6 +112,8 @@ EXPORTS = {
     "nmtgan_add_layernorm": (i32, [C.POINTER(AddLnArgs), vp]),
     "nmtgan_attn_rows": (i32, [C.POINTER(AttnArgs), vp]),
     "nmtgan_sample_rows": (i32, [C.POINTER(SampleArgs), vp]),
+    "nmtgan_attn_group": (i32, [C.POINTER(AttnGroupArgs), vp]),
+    "nmtgan_transpose_v": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "nmtgan_disc_workspace_bytes": (sz, [C.POINTER(Discriminator), i32]),
     "nmtgan_disc_features": (i32, [C.POINTER(Discriminator), i32, vp, i32, vp, i32, vp, sz, vp]),
     "nmtgan_disc_head": (i32, [C.POINTER(Discriminator), vp, vp, vp, i32, vp, vp, vp]),

@@ -81,6 +81,12 @@ int nmtgan_add_layernorm(const nmtgan_addln_args* a, void* stream) {
   return launch_add_layernorm(a, (hipStream_t)stream);
 }
 int nmtgan_attn_rows(const nmtgan_attn_args* a, void* stream) { return launch_attn_rows(a, (hipStream_t)stream); }
+int nmtgan_attn_group(const nmtgan_attn_group_args* a, void* stream) {
+  return launch_attn_group(a, (hipStream_t)stream);
+}
+int nmtgan_transpose_v(const void* v, void* vt, int nblk, int len, int len_padded, int d, void* stream) {
+  return launch_transpose_v(v, vt, nblk, len, len_padded, d, (hipStream_t)stream);
+}
 int nmtgan_sample_rows(const nmtgan_sample_args* a, void* stream) {
   return launch_sample_rows(a, (hipStream_t)stream);
 }

@@ -19,6 +19,7 @@ struct AttnParams {
   const uint8_t* mask1;
   const void* k2; const void* v2; const int64_t* step_off; int n_steps2;
   void* out;
+  const float* o_init; const float* m_init; const float* l_init;
 };
 
 template <typename KT, int EPL, int KB>
@@ -45,6 +46,12 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
   float o[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+  if (p.o_init) {                                      // continue from the group kernel's state
+    const int head = (lane * EPL) / (d / p.heads);
+    m = p.m_init[(int64_t)row * p.heads + head];
+    l = p.l_init[(int64_t)row * p.heads + head];
+    VecIO<float, EPL>::load(p.o_init + (int64_t)row * d + lane * EPL, o);
+  }
 
   for (int jb = 0; jb < n_total; jb += KB) {
     float kf[KB][EPL], vf[KB][EPL];
@@ -135,8 +142,10 @@ int launch_attn_rows(const nmtgan_attn_args* a, hipStream_t st) {
   NMTGAN_REQUIRE(!(a->causal && !a->seg1_cnt) || (a->rows_per_blk > 0 && a->rows_per_blk <= a->len1),
                  "attn: causal needs rows_per_blk <= len1");
   NMTGAN_REQUIRE(a->n_steps2 == 0 || (a->k2 && a->v2 && a->step_off), "attn: segment 2 incomplete");
+  NMTGAN_REQUIRE((!a->o_init && !a->m_init && !a->l_init) || (a->o_init && a->m_init && a->l_init),
+                 "attn: o_init/m_init/l_init must be given together");
   AttnParams p{a->q, a->M, a->d, a->heads, a->k1, a->v1, a->len1, a->seg1_blk, a->seg1_cnt, a->rows_per_blk,
-               a->causal, a->mask1, a->k2, a->v2, a->step_off, a->n_steps2, a->out};
+               a->causal, a->mask1, a->k2, a->v2, a->step_off, a->n_steps2, a->out, a->o_init, a->m_init, a->l_init};
   if (a->kv_dtype == NMTGAN_BF16) return launch_attn_t<bf16_t>(p, st);
   if (a->kv_dtype == NMTGAN_F32) return launch_attn_t<float>(p, st);
   NMTGAN_FAIL(-2, "attn: bad kv_dtype %d", a->kv_dtype);

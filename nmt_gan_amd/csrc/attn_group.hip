@@ -1,0 +1,200 @@
+// Group attention for gfx950 (bf16 tier): the R rollouts of one (sentence, prefix) group share their
+// keys - the teacher-forced prefix of the sentence, or the encoder memory - so one workgroup loads
+// every K/V element ONCE for all R query rows and does the arithmetic on the matrix cores.
+//
+// Per head, per tile of 32 keys (v_mfma_f32_32x32x16_bf16 throughout):
+//   S^T[key, row] = K[key, :] . Q[row, :]^T     A = K rows straight from global (16 B per lane),
+//                                               B = Q rows (fp32 -> bf16 once per head)
+//   online softmax along the keys: a query row is a lane column of the accumulator, its 32 keys sit
+//   in the 16 registers of the two half-waves -> in-lane reductions + one cross-half exchange
+//   O^T[dv, row] += V^T[dv, key] . P^T[key, row]  B = the S^T accumulator itself, converted to bf16
+//                                               in place (guide section 3, "accumulator tile as the
+//                                               next MFMA's operand"); A = V^T, which is why shared
+//                                               V is kept TRANSPOSED in HBM: [block][d][Lp].
+// Outputs either the normalised attention (cross-attention) or the un-normalised state (o, m, l)
+// that attn_rows_kernel continues with over the row's private suffix keys (rollout self-attention).
+// Replaces dot_product_attention (common_attention.py:294-331) for the shared-key part.
+#include "common.h"
+#include "kernels.h"
+
+namespace nmtgan {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+struct GroupAttnParams {
+  const float* q;              // [M][d] fp32, already scaled
+  int M, d, heads, R;          // R rows per group (<= 32)
+  const bf16_t* k;             // [nblk][L][d]
+  const bf16_t* vt;            // [nblk][d][Lp]
+  int L, Lp;
+  const int32_t* row_blk;      // [M] block of a row (read at the group's first row)
+  const int32_t* row_cnt;      // [M] keys of a row, or NULL -> L
+  const uint8_t* mask;         // [nblk][L] or NULL
+  bf16_t* out;                 // [M][d] normalised output (final mode) or NULL
+  float* o_part; float* m_part; float* l_part;   // partial mode: [M][d], [M][heads], [M][heads]
+};
+
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
+  return r;
+}
+
+template <int DK>
+__global__ __launch_bounds__(256) void attn_group_kernel(GroupAttnParams p) {
+  constexpr int KS = DK / 16;      // k-steps of the QK^T product
+  constexpr int DT = DK / 32;      // 32-row tiles of O^T
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, h2 = lane >> 5;
+  const int row0 = blockIdx.x * p.R;
+  const int row = row0 + n;
+  const bool row_ok = n < p.R && row < p.M;
+  const int blk = p.row_blk[row0];
+  const int cnt = p.row_cnt ? p.row_cnt[row0] : p.L;
+  const int d = p.d;
+  const uint8_t* mk = p.mask ? p.mask + (int64_t)blk * p.L : nullptr;
+
+  for (int head = wave; head < p.heads; head += 4) {
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      float t[8];
+      if (row_ok) VecIO<float, 8>::load(p.q + (int64_t)row * d + head * DK + 16 * s + 8 * h2, t);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = 0.f;
+      }
+      qf[s] = pack8(t);
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const bf16_t* Kb = p.k + (int64_t)blk * p.L * d + head * DK + 8 * h2;
+    const bf16_t* Vb = p.vt + ((int64_t)blk * d + head * DK + n) * p.Lp + 4 * h2;
+
+    for (int k0 = 0; k0 < cnt; k0 += 32) {
+      f32x16 sacc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+      const int keyc = min(k0 + n, p.L - 1);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint4 kv = *reinterpret_cast<const uint4*>(Kb + (int64_t)keyc * d + 16 * s);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kv), qf[s], sacc, 0, 0, 0);
+      }
+      float sv[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int kk = k0 + (e & 3) + 8 * (e >> 2) + 4 * h2;
+        const bool ok = kk < cnt && !(mk && mk[min(kk, p.L - 1)]);
+        sv[e] = ok ? sacc[e] : -INFINITY;
+        mx = fmaxf(mx, sv[e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m, mx);
+      if (m_new == -INFINITY) continue;           // every key of the tile masked (same for all lanes)
+      const float alpha = __expf(m - m_new);
+      float pv[16];
+      float ls = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        pv[e] = __expf(sv[e] - m_new);
+        ls += pv[e];
+      }
+      ls += __shfl_xor(ls, 32, 64);
+      l = l * alpha + ls;
+      m = m_new;
+      bf16x8 pf[2] = {pack8(pv), pack8(pv + 8)};
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          // element j of half h2 must be key 16s + 8(j>>2) + 4*h2 + (j&3) (operand k-order of the acc tile)
+          const bf16_t* vp = Vb + (int64_t)(32 * t) * p.Lp + k0 + 16 * s;
+          const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+          const uint2 hi = *reinterpret_cast<const uint2*>(vp + 8);
+          const uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s], o[t], 0, 0, 0);
+        }
+      }
+    }
+    if (!row_ok) continue;
+    // O^T tile t: this lane = query row n, register e = dv 32t + (e&3) + 8(e>>2) + 4*h2
+    if (p.out) {
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float v4[4] = {o[t][4 * c] * inv, o[t][4 * c + 1] * inv, o[t][4 * c + 2] * inv, o[t][4 * c + 3] * inv};
+          VecIO<bf16_t, 4>::store(p.out + (int64_t)row * d + head * DK + 32 * t + 8 * c + 4 * h2, v4);
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float v4[4] = {o[t][4 * c], o[t][4 * c + 1], o[t][4 * c + 2], o[t][4 * c + 3]};
+          VecIO<float, 4>::store(p.o_part + (int64_t)row * d + head * DK + 32 * t + 8 * c + 4 * h2, v4);
+        }
+      if (h2 == 0) {
+        p.m_part[(int64_t)row * p.heads + head] = m;
+        p.l_part[(int64_t)row * p.heads + head] = l;
+      }
+    }
+  }
+}
+
+// V [nblk*L][d] -> V^T [nblk][d][Lp], zero padded to Lp (multiple of 32, >= L)
+__global__ void transpose_v_kernel(const bf16_t* v, bf16_t* vt, int nblk, int L, int Lp, int d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)nblk * d * Lp) return;
+  const int t = (int)(i % Lp);
+  const int c = (int)((i / Lp) % d);
+  const int b = (int)(i / ((int64_t)Lp * d));
+  vt[i] = t < L ? v[((int64_t)b * L + t) * d + c] : (bf16_t)0;
+}
+
+int launch_transpose_v(const void* v, void* vt, int nblk, int L, int Lp, int d, hipStream_t st) {
+  prof::Scope prof_scope(prof::OTHER, st);
+  NMTGAN_REQUIRE(v && vt && nblk > 0 && L > 0 && Lp >= L && Lp % 32 == 0 && d > 0, "transpose_v: bad arguments");
+  const int64_t n = (int64_t)nblk * d * Lp;
+  hipLaunchKernelGGL(transpose_v_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)v,
+                     (bf16_t*)vt, nblk, L, Lp, d);
+  NMTGAN_CHECK_LAUNCH("transpose_v");
+  return 0;
+}
+
+int launch_attn_group(const nmtgan_attn_group_args* a, hipStream_t st) {
+  prof::Scope prof_scope(prof::ATTN_PREFILL, st);
+  NMTGAN_REQUIRE(a != nullptr, "attn_group: null args");
+  if (a->M == 0) return 0;
+  NMTGAN_REQUIRE(a->M > 0 && a->d > 0 && a->heads > 0 && a->d % a->heads == 0, "attn_group: bad M/d/heads");
+  NMTGAN_REQUIRE(a->rows_per_group > 0 && a->rows_per_group <= 32 && a->M % a->rows_per_group == 0,
+                 "attn_group: rows_per_group must be 1..32 and divide M");
+  NMTGAN_REQUIRE(a->q && a->k && a->vt && a->row_blk, "attn_group: null pointer");
+  NMTGAN_REQUIRE(a->len > 0 && a->len_padded >= a->len && a->len_padded % 32 == 0, "attn_group: bad key lengths");
+  NMTGAN_REQUIRE((a->out != nullptr) != (a->o_part != nullptr), "attn_group: exactly one of out / o_part");
+  NMTGAN_REQUIRE(a->out || (a->m_part && a->l_part), "attn_group: partial mode needs m_part and l_part");
+  GroupAttnParams p{a->q, a->M, a->d, a->heads, a->rows_per_group, (const bf16_t*)a->k, (const bf16_t*)a->vt, a->len,
+                    a->len_padded, a->row_blk, a->row_cnt, a->mask, (bf16_t*)a->out, a->o_part, a->m_part, a->l_part};
+  dim3 grid(a->M / a->rows_per_group), block(256);
+  switch (a->d / a->heads) {
+    case 32: hipLaunchKernelGGL(attn_group_kernel<32>, grid, block, 0, st, p); break;
+    case 64: hipLaunchKernelGGL(attn_group_kernel<64>, grid, block, 0, st, p); break;
+    case 128: hipLaunchKernelGGL(attn_group_kernel<128>, grid, block, 0, st, p); break;
+    default: NMTGAN_FAIL(-2, "attn_group: head dim %d not in {32, 64, 128}", a->d / a->heads);
+  }
+  NMTGAN_CHECK_LAUNCH("attn_group");
+  return 0;
+}
+
+}  // namespace nmtgan

@@ -127,6 +127,10 @@ struct DecAttn {
   const void* crossK; const void* crossV; int Ls; int64_t cross_layer_stride;
   const int32_t* cross_blk; int cross_rows_per_blk; const uint8_t* x_pad;
   int step_mode;   // 1: rollout step (profile classes attn_self/attn_cross), 0: prefill
+  // group path (bf16 rollout steps): R consecutive rows share their segment-1 keys -> MFMA kernel
+  int group_R; const void* shVt; int sh_Lp; int64_t sht_layer_stride;
+  const void* crossVt; int cross_Lp; int64_t crosst_layer_stride;
+  float* o_part; float* m_part; float* l_part;
 };
 
 static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn& c, hipStream_t st) {
@@ -141,7 +145,22 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       float sc[3] = {qscale, 1.f, 1.f};
       NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st));
     }
-    {
+    if (c.group_R > 0) {
+      // shared prefix keys once per group on MFMA -> running (o, m, l); private suffix per row after
+      nmtgan_attn_group_args ga{};
+      ga.q = a.q; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
+      ga.k = at(c.shK, l * c.sh_layer_stride, es); ga.vt = at(c.shVt, l * c.sht_layer_stride, es);
+      ga.len = c.len_sh; ga.len_padded = c.sh_Lp; ga.row_blk = c.seg1_blk; ga.row_cnt = c.seg1_cnt;
+      ga.o_part = c.o_part; ga.m_part = c.m_part; ga.l_part = c.l_part;
+      prof::Hint ph(prof::ATTN_SELF);
+      NMTGAN_TRY(launch_attn_group(&ga, st));
+      nmtgan_attn_args t{};
+      t.q = a.q; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
+      t.k2 = at(c.prK, l * c.pr_layer_stride, es); t.v2 = at(c.prV, l * c.pr_layer_stride, es);
+      t.step_off = c.step_off; t.n_steps2 = c.n_steps2;
+      t.o_init = c.o_part; t.m_init = c.m_part; t.l_init = c.l_part; t.out = a.ao;
+      NMTGAN_TRY(launch_attn_rows(&t, st));
+    } else {
       nmtgan_attn_args t{};
       t.q = a.q; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
       if (c.shK) {
@@ -160,7 +179,14 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
     NMTGAN_TRY(dense1(op, a.ao, d, M, d, d, b.o, a.yf, d, 1, 1.f, 0, st));
     NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln0, M, a.xo, nullptr, st));
     NMTGAN_TRY(dense1(op, a.xo, d, M, d, d, b.cq, a.q, d, 1, qscale, 0, st));
-    {
+    if (c.group_R > 0) {
+      nmtgan_attn_group_args ga{};
+      ga.q = a.q; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
+      ga.k = at(c.crossK, l * c.cross_layer_stride, es); ga.vt = at(c.crossVt, l * c.crosst_layer_stride, es);
+      ga.len = c.Ls; ga.len_padded = c.cross_Lp; ga.row_blk = c.cross_blk; ga.mask = c.x_pad; ga.out = a.ao;
+      prof::Hint ph(prof::ATTN_CROSS);
+      NMTGAN_TRY(launch_attn_group(&ga, st));
+    } else {
       nmtgan_attn_args t{};
       t.q = a.q; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
       t.k1 = at(c.crossK, l * c.cross_layer_stride, es); t.v1 = at(c.crossV, l * c.cross_layer_stride, es);
@@ -290,6 +316,7 @@ int disc_features(const nmtgan_discriminator* d, int source, const int32_t* ids,
 struct RewardBufs {
   Act act;
   void *kbuf, *vbuf, *crossK, *crossV, *shK, *shV, *prK, *prV;
+  void *shVt, *crossVt; float *o_part, *m_part, *l_part; int group_R, Tp, Lsp;
   float* logits; float* prefix_logits;
   int32_t* Y; int32_t* tok_cur;
   float *feat_s, *feat_t, *p_rows, *p_base;
@@ -312,6 +339,21 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   b.crossV = ar.take(N * enc_rows * dm * es);
   b.shK = ar.take(N * pre_rows * dm * es);
   b.shV = ar.take(N * pre_rows * dm * es);
+  // group attention path: bf16, <= 32 rollouts per (sentence, prefix) group, MFMA-friendly head dim
+  const int dk = dm / g->heads;
+  b.group_R = (g->op_dtype == NMTGAN_BF16 && p->rollnum <= 32 && (dk == 32 || dk == 64 || dk == 128) &&
+               p->n_steps >= 1) ? p->rollnum : 0;
+  b.Tp = (p->T + 31) / 32 * 32;
+  b.Lsp = (p->Ls + 31) / 32 * 32;
+  b.shVt = b.crossVt = nullptr;
+  b.o_part = b.m_part = b.l_part = nullptr;
+  if (b.group_R > 0) {
+    b.shVt = ar.take((size_t)N * p->B * dm * b.Tp * es);
+    b.crossVt = ar.take((size_t)N * p->B * dm * b.Lsp * es);
+    b.o_part = ar.get<float>(act_rows * dm);
+    b.m_part = ar.get<float>(act_rows * g->heads);
+    b.l_part = ar.get<float>(act_rows * g->heads);
+  }
   b.pr_rows = p->n_steps >= 1 ? p->step_off_host[p->n_steps] : 0;
   b.prK = ar.take((size_t)N * b.pr_rows * dm * es);
   b.prV = ar.take((size_t)N * b.pr_rows * dm * es);
@@ -386,6 +428,15 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
   // 2. teacher-forced pass over y_sample: shared K/V of positions 0..T-1 and the prefix logits
   NMTGAN_TRY(prefill(g, p->dec_in, p->x_pad, B, Ls, T, b.act, b.shK, b.shV, b.crossK, b.crossV, st));
   NMTGAN_TRY(logits_gemm(g, b.act.xo, B * T, b.prefix_logits, st));
+  if (b.group_R > 0) {                 // transposed copies of the shared values for the MFMA group kernel
+    const int es = dtype_size(op);
+    for (int l = 0; l < g->n_blocks; ++l) {
+      NMTGAN_TRY(launch_transpose_v(at(b.shV, (int64_t)l * B * T * dm, es), at(b.shVt, (int64_t)l * B * dm * b.Tp, es), B,
+                                    T, b.Tp, dm, st));
+      NMTGAN_TRY(launch_transpose_v(at(b.crossV, (int64_t)l * B * Ls * dm, es),
+                                    at(b.crossVt, (int64_t)l * B * dm * b.Lsp, es), B, Ls, b.Lsp, dm, st));
+    }
+  }
   // 3. rollouts
   if (p->n_rows > 0) {
     NMTGAN_TRY(launch_init_rollouts(p->y, p->row_b, p->row_g, p->n_rows, T, b.Y, st));
@@ -410,6 +461,9 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
       c.wrK = b.prK; c.wrV = b.prV; c.wr_layer_stride = b.pr_rows * dm; c.wr_off = p->step_off_host[step - 1] * dm;
       c.crossK = b.crossK; c.crossV = b.crossV; c.Ls = Ls; c.cross_layer_stride = (int64_t)B * Ls * dm;
       c.cross_blk = p->row_b; c.x_pad = p->x_pad; c.step_mode = 1;
+      c.group_R = b.group_R; c.shVt = b.shVt; c.sh_Lp = b.Tp; c.sht_layer_stride = (int64_t)B * dm * b.Tp;
+      c.crossVt = b.crossVt; c.cross_Lp = b.Lsp; c.crosst_layer_stride = (int64_t)B * dm * b.Lsp;
+      c.o_part = b.o_part; c.m_part = b.m_part; c.l_part = b.l_part;
       NMTGAN_TRY(decoder_pass(g, M, b.act, c, st));
       for (int r0 = 0; r0 < M; r0 += (int)b.logits_rows) {
         const int rows = M - r0 < b.logits_rows ? M - r0 : (int)b.logits_rows;

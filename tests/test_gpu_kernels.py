@@ -299,3 +299,75 @@ def test_reward_reduce(cuda):
                     q = np.float32(q - np.float32(bias * R))
                 want[b, t] = np.float32(np.float32(q * mask[b, t]) / np.float32(R))
         assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("d,heads,R", [(128, 2, 16), (512, 8, 16), (1024, 16, 20), (128, 4, 3)])
+def test_attn_group_final_and_partial(cuda, d, heads, R):
+    """MFMA group attention (shared keys, bf16) in both output modes: normalised output (cross
+    attention with a padding mask) and running state continued by attn_rows over private keys."""
+    L = _lib()
+    g = torch.Generator().manual_seed(d + R)
+    nblk, len1 = 4, 50
+    Lp = 64
+    G = 7                                   # groups
+    M = G * R
+    q = (torch.randn(M, d, generator=g) * 0.3).to(cuda)
+    k1 = torch.randn(nblk, len1, d, generator=g).bfloat16().to(cuda)
+    v1 = torch.randn(nblk, len1, d, generator=g).bfloat16().to(cuda)
+    vt = torch.full((nblk, d, Lp), float("nan"), dtype=torch.bfloat16, device=cuda)
+    L.check(L.lib.nmtgan_transpose_v(v1.data_ptr(), vt.data_ptr(), nblk, len1, Lp, d, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(vt[:, :, :len1], v1.transpose(1, 2)) and vt[:, :, len1:].abs().max().item() == 0
+    gblk = torch.randint(0, nblk, (G,), generator=g, dtype=torch.int32)
+    gcnt = torch.tensor([1, 2, 31, 32, 33, 50, 17], dtype=torch.int32)
+    blk = gblk.repeat_interleave(R).to(cuda)
+    cnt = gcnt.repeat_interleave(R).to(cuda)
+    mask = torch.zeros(nblk, len1, dtype=torch.uint8)
+    mask[:, 40:] = 1
+    mask[1, 0] = 1
+    mask_d = mask.to(cuda)
+
+    def ref_row(r, use_mask, extra_k=None, extra_v=None):
+        b, c = int(blk[r]), int(cnt[r])
+        keep = [j for j in range(c) if not (use_mask and int(mask[b, j]))]
+        ks, vs = [k1[b, j] for j in keep], [v1[b, j] for j in keep]
+        if extra_k is not None:
+            ks += extra_k
+            vs += extra_v
+        return _attn_ref(q[r].double().cpu(), torch.stack(ks).double().cpu(), torch.stack(vs).double().cpu(), heads)
+
+    # --- final mode with mask (counts = full length, like cross attention)
+    out = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device=cuda)
+    a = L.AttnGroupArgs()
+    a.q, a.M, a.d, a.heads, a.rows_per_group = q.data_ptr(), M, d, heads, R
+    a.k, a.vt, a.len, a.len_padded = k1.data_ptr(), vt.data_ptr(), len1, Lp
+    a.row_blk, a.row_cnt, a.mask, a.out = blk.data_ptr(), cnt.data_ptr(), mask_d.data_ptr(), out.data_ptr()
+    rows_ok = [r for r in range(M) if any(not int(mask[int(blk[r]), j]) for j in range(int(cnt[r])))]
+    L.check(L.lib.nmtgan_attn_group(C.byref(a), L.stream_ptr()))
+    torch.cuda.synchronize()
+    for r in rows_ok[::3]:
+        err = (out[r].double().cpu() - ref_row(r, True)).abs().max().item()
+        assert err < 3e-2, (r, err)            # bf16 q / p / output rounding
+    # --- partial mode, continued over 3 private keys by attn_rows
+    o_part = torch.empty(M, d, device=cuda)
+    m_part = torch.empty(M, heads, device=cuda)
+    l_part = torch.empty(M, heads, device=cuda)
+    a.mask, a.out = None, None
+    a.o_part, a.m_part, a.l_part = o_part.data_ptr(), m_part.data_ptr(), l_part.data_ptr()
+    L.check(L.lib.nmtgan_attn_group(C.byref(a), L.stream_ptr()))
+    nsteps = 3
+    step_off = torch.tensor([0, M, 2 * M, 3 * M], dtype=torch.int64, device=cuda)
+    k2 = torch.randn(nsteps * M, d, generator=g).bfloat16().to(cuda)
+    v2 = torch.randn(nsteps * M, d, generator=g).bfloat16().to(cuda)
+    out2 = torch.empty(M, d, dtype=torch.bfloat16, device=cuda)
+    b = L.AttnArgs()
+    b.q, b.M, b.d, b.heads, b.kv_dtype = q.data_ptr(), M, d, heads, L.NMTGAN_BF16
+    b.k2, b.v2, b.step_off, b.n_steps2 = k2.data_ptr(), v2.data_ptr(), step_off.data_ptr(), nsteps
+    b.o_init, b.m_init, b.l_init, b.out = o_part.data_ptr(), m_part.data_ptr(), l_part.data_ptr(), out2.data_ptr()
+    L.check(L.lib.nmtgan_attn_rows(C.byref(b), L.stream_ptr()))
+    torch.cuda.synchronize()
+    for r in range(0, M, 5):
+        ek = [k2[s * M + r] for s in range(nsteps)]
+        ev = [v2[s * M + r] for s in range(nsteps)]
+        err = (out2[r].double().cpu() - ref_row(r, False, ek, ev)).abs().max().item()
+        assert err < 3e-2, (r, err)

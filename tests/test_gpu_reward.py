@@ -20,9 +20,22 @@ B = 5
 R = 3
 
 
+_SETUPS = {}
+
+
+def _make_setup(d, heads):
+    if (d, heads) not in _SETUPS:
+        _SETUPS[(d, heads)] = _build_setup(d, heads)
+    return _SETUPS[(d, heads)]
+
+
 @pytest.fixture(scope="module")
 def setup():
-    gcfg, dcfg = tiny_cfgs(T=T)
+    return _make_setup(64, 4)
+
+
+def _build_setup(d, heads):
+    gcfg, dcfg = tiny_cfgs(d=d, heads=heads, T=T)
     Wg = O.init_generator_weights(gcfg, 0)
     Wd = disc_weights(dcfg, 1)
     x, y = O.synthetic_batch(B, T, gcfg.src_vocab_size, gcfg.dst_vocab_size, seed=1234, eos_rows=(1, 3),
@@ -115,10 +128,13 @@ def test_get_reward_no_bias_fp32(cuda, setup):
     assert np.abs(r - ref).max() < 1e-5
 
 
-def test_get_reward_bf16_token_agreement_and_rewards(cuda, setup):
+@pytest.mark.parametrize("d,heads", [(64, 4), (128, 4)])
+def test_get_reward_bf16_token_agreement_and_rewards(cuda, d, heads):
     """bf16 tier: tokens checked per step under forced-identical prefixes - the oracle replays each
-    GPU rollout (teacher-forced) and re-samples every position with the same uniform."""
-    s = setup
+    GPU rollout (teacher-forced) and re-samples every position with the same uniform.
+    d=64/h=4 (head dim 16) runs the per-row attention kernel, d=128/h=4 (head dim 32) the MFMA
+    group-attention path used by the production shapes."""
+    s = _make_setup(d, heads)
     r, det = _gpu_reward(s, "bf16")
     plan = det["plan"]
     n = plan.n_rows
