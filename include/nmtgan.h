@@ -182,6 +182,17 @@ typedef struct {
 int nmtgan_sample_rows(const nmtgan_sample_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused logits + sampling: out[r] = sample(softmax(x[r] . w^T), u(r)) without writing the logits
+ * (model.py:226-241: top() -> slice -> softmax -> log -> tf.multinomial).  x[M][d], w[V][d] in op
+ * dtype; V % 64 == 0, d*esize % 128 == 0 and >= 512 bytes (else use nmtgan_gemm + nmtgan_sample_rows).
+ * Same CDF semantics as nmtgan_sample_rows, accumulated per 64-entry vocabulary tile in fp64.
+ */
+size_t nmtgan_logits_sample_workspace_bytes(int M, int V);
+int nmtgan_logits_sample(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
+                         const int64_t* u_off, int64_t u_add, int32_t* out, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Packed models.  All matrices Wt[N][K] in op dtype; biases / LN / BN-folded vectors fp32.
  */
 typedef struct {

@@ -87,6 +87,16 @@ int nmtgan_attn_group(const nmtgan_attn_group_args* a, void* stream) {
 int nmtgan_transpose_v(const void* v, void* vt, int nblk, int len, int len_padded, int d, void* stream) {
   return launch_transpose_v(v, vt, nblk, len, len_padded, d, (hipStream_t)stream);
 }
+size_t nmtgan_logits_sample_workspace_bytes(int M, int V) { return (M > 0 && V > 0) ? logits_sample_workspace(M, V) : 0; }
+int nmtgan_logits_sample(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
+                         const int64_t* u_off, int64_t u_add, int32_t* out, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (M > 0 && (!gemm_stats_supported(op_dtype, V, d) || workspace_bytes < logits_sample_workspace(M, V))) {
+    set_error("logits_sample: unsupported shape (V %% 64, d*esize %% 128, >= 4 k-tiles) or workspace too small");
+    return -2;
+  }
+  return launch_logits_sample(op_dtype, x, w, M, V, d, u, u_off, u_add, out, workspace, (hipStream_t)stream);
+}
 int nmtgan_sample_rows(const nmtgan_sample_args* a, void* stream) {
   return launch_sample_rows(a, (hipStream_t)stream);
 }

@@ -47,7 +47,10 @@ struct GemmParams {
   void* out[3]; int64_t ldo[3]; int out_f32[3]; float seg_scale[3];
   // convmax epilogue
   const float* scale; const float* shift; float* pooled; int64_t ld_pool;
+  // stats epilogue (fused sampling)
+  float2* stats;
 };
+constexpr int EPI_STATS = 2;
 
 template <typename OpT>
 __device__ __forceinline__ void mma_chunk(const uint4& a, const uint4& b, f32x16& c);
@@ -280,6 +283,34 @@ __device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x16 (&acc)
   }
 }
 
+// STATS epilogue (fused sampling, logits never reach HBM).  The GEMM runs TRANSPOSED: C rows = vocab
+// entries (A = softmax table), C columns = decoder rows (Wt = activations), so a decoder row is a
+// lane column of the accumulator and its 64 logits of this wave tile sit in the 2x16 registers of
+// the two half-waves: tile max and sum of exp(l - max) are in-lane reductions plus one cross-half
+// exchange.  stats[vtile][row] = (max, sum) with vtile = vocab/64; launch_logits_sample turns them
+// into a sampled token (sampler.hip).
+__device__ __forceinline__ void epilogue_stats(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int lane) {
+  if (m0 >= p.M) return;                           // vocab size is a multiple of 64: whole tile in or out
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[i][j][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f((acc[i][j][e] - mx) * 1.44269504088896341f);
+    sum += __shfl_xor(sum, 32, 64);
+    const int row = n0 + j * 32 + fr;
+    if (fh == 0 && row < p.N) p.stats[(int64_t)(m0 >> 6) * p.N + row] = make_float2(mx, sum);
+  }
+}
+
 template <typename OpT, int EPI>
 __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -374,7 +405,9 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
     const int m0 = tm * PBM + wm * 64, n0 = tn * PBN + wn * 64;
     bool wide = false;
     if constexpr (EPI == NMTGAN_EPI_LINEAR) wide = p.wide_ok && n0 < p.N;
-    if (wide) {
+    if constexpr (EPI == EPI_STATS) {
+      epilogue_stats(p, acc, m0, n0, lane);
+    } else if (wide) {
       const int seg = (p.n_seg > 1) ? n0 / p.seg_width : 0;
       const bool f32_out = p.out_f32[seg] != 0 || sizeof(OpT) == 4;
       epilogue_wide<OpT>(p, acc, m0, n0, lane, scr, f32_out, seg, n0 - seg * p.seg_width);
@@ -548,6 +581,25 @@ static int dispatch(const GemmParams& p, hipStream_t st) {
   if (pipe_ok && (ov == 3 || (ov < 0 && tiles256 >= 192))) return launch_pipe<OpT, EPI>(p, st);
   if (ov == 256) return launch_glds<OpT, EPI, 256, 128>(p, st);
   return launch_glds<OpT, EPI, 128, 128>(p, st);
+}
+
+// logits^T = W[V,K] . X[rows,K]^T reduced on the fly to per-(64-vocab tile, row) softmax statistics
+int launch_gemm_stats(int op_dtype, const void* W, int V, const void* X, int rows, int K, float2* stats,
+                      hipStream_t st) {
+  prof::Scope prof_scope(prof::GEMM_LOGITS, st);
+  const int es = dtype_size(op_dtype);
+  NMTGAN_REQUIRE(W && X && stats && V > 0 && rows > 0 && K > 0, "gemm_stats: bad arguments");
+  NMTGAN_REQUIRE(V % 64 == 0 && (K * es) % BKB == 0 && (K * es) / BKB >= 4, "gemm_stats: unsupported shape");
+  GemmParams p{};
+  p.A = (const char*)W; p.W = (const char*)X;
+  p.M = V; p.N = rows; p.K = K;
+  p.lda_b = (int64_t)K * es; p.ldw_b = (int64_t)K * es; p.kbytes = K * es;
+  p.stats = stats;
+  return op_dtype == NMTGAN_BF16 ? launch_pipe<bf16_t, EPI_STATS>(p, st) : launch_pipe<float, EPI_STATS>(p, st);
+}
+bool gemm_stats_supported(int op_dtype, int V, int K) {
+  const int es = dtype_size(op_dtype);
+  return V % 64 == 0 && V <= 65536 && (K * es) % BKB == 0 && (K * es) / BKB >= 4;   // <= 1024 vocabulary tiles
 }
 
 int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st) {

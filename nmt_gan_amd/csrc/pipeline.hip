@@ -318,6 +318,7 @@ struct RewardBufs {
   void *kbuf, *vbuf, *crossK, *crossV, *shK, *shV, *prK, *prV;
   void *shVt, *crossVt; float *o_part, *m_part, *l_part; int group_R, Tp, Lsp;
   float* logits; float* prefix_logits;
+  void* fused_ws; bool fused;                 // logits never materialised during the rollout steps
   int32_t* Y; int32_t* tok_cur;
   float *feat_s, *feat_t, *p_rows, *p_base;
   DiscBufs disc;
@@ -360,6 +361,10 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   int64_t lrows = p->logits_chunk_rows > 0 ? p->logits_chunk_rows : 4096;
   if (p->n_steps >= 1 && p->live[1] < lrows) lrows = p->live[1];
   if (lrows < 1) lrows = 1;
+  static const bool fused_env = [] { const char* e = getenv("NMTGAN_FUSED_SAMPLE"); return !e || atoi(e) != 0; }();
+  b.fused = fused_env && p->n_steps >= 1 && gemm_stats_supported(g->op_dtype, g->vocab_dst, dm);
+  b.fused_ws = b.fused ? ar.take(logits_sample_workspace(p->live[1], g->vocab_dst)) : nullptr;
+  if (b.fused) lrows = 1;
   b.logits_rows = lrows;
   b.logits = ar.get<float>(lrows * g->vocab_dst);
   b.prefix_logits = p->prefix_logits ? p->prefix_logits : ar.get<float>(pre_rows * g->vocab_dst);
@@ -465,7 +470,10 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
       c.crossVt = b.crossVt; c.cross_Lp = b.Lsp; c.crosst_layer_stride = (int64_t)B * dm * b.Lsp;
       c.o_part = b.o_part; c.m_part = b.m_part; c.l_part = b.l_part;
       NMTGAN_TRY(decoder_pass(g, M, b.act, c, st));
-      for (int r0 = 0; r0 < M; r0 += (int)b.logits_rows) {
+      if (b.fused) {
+        NMTGAN_TRY(launch_logits_sample(op, b.act.xo, g->softmax_w, M, V, dm, p->uniforms, p->row_uoff, step, b.tok_cur,
+                                        b.fused_ws, st));
+      } else for (int r0 = 0; r0 < M; r0 += (int)b.logits_rows) {
         const int rows = M - r0 < b.logits_rows ? M - r0 : (int)b.logits_rows;
         NMTGAN_TRY(logits_gemm(g, at(b.act.xo, (int64_t)r0 * dm, dtype_size(op)), rows, b.logits, st));
         nmtgan_sample_args q{};

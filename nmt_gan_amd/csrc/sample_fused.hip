@@ -1,0 +1,290 @@
+// Fused logits + categorical sampling for gfx950: the rollout step's [rows, V] logits never reach HBM.
+// Replaces top() -> softmax -> log -> tf.multinomial of the rollout loop (model.py:226-241) with the
+// same CDF semantics as sampler.hip (fp64 running sum of exp(l - max l) in index order, first index
+// whose CDF exceeds u * total, clamp to V-1):
+//   1. launch_gemm_stats (gemm.hip, transposed logits GEMM): stats[vtile][row] = (max, sum exp(l - max))
+//      over each 64-entry vocabulary tile - 8 bytes instead of 256 per (tile, row).
+//   2. select_kernel: 16 lanes per row read the row's tile stats ONCE into registers, combine them into
+//      the tile-granular fp64 CDF and find the tile where u * total is crossed; counts rows per tile.
+//   3. worklist_kernel + scatter_kernel: counting sort of the rows by selected tile (no host sync: the
+//      work list has a static upper bound of n_vtile + rows/32 entries).
+//   4. recompute_kernel: one wave per (tile, <= 32 rows) recomputes exactly those 64 x 32 logits on the
+//      matrix cores (operands straight from global: the softmax table tile is shared by the 32 rows)
+//      and finishes the upper_bound inside the tile.
+// A miss caused by the ~1e-6 mismatch between the two evaluations of a logit takes the tile's last entry.
+// HBM bytes per sampled token: ~2 x 8 x V/64 (stats) + 2 KB, against 2 x 4 x V for materialised logits.
+#include "common.h"
+#include "kernels.h"
+
+namespace nmtgan {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
+struct FusedBufs {
+  float2* stats;           // [n_vtile][M]
+  double* sel_pre;         // [M] CDF mass before the selected tile
+  double* sel_target;      // [M] u * total
+  float* sel_max;          // [M] row max
+  int32_t* sel_tile;       // [M]
+  int32_t* count;          // [1024] rows per tile
+  int32_t* tile_off;       // [1024]
+  int32_t* cursor;         // [1024]
+  int32_t* n_work;         // [1]
+  int2* work;              // [n_vtile + M/32 + 1] (tile, chunk)
+  int32_t* order;          // [M] rows sorted by tile
+};
+
+static size_t carve_fused(char* base, int M, int V, FusedBufs& b) {
+  const size_t nvt = V / 64;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+  b.stats = (float2*)take(nvt * M * sizeof(float2));
+  b.sel_pre = (double*)take((size_t)M * sizeof(double));
+  b.sel_target = (double*)take((size_t)M * sizeof(double));
+  b.sel_max = (float*)take((size_t)M * sizeof(float));
+  b.sel_tile = (int32_t*)take((size_t)M * sizeof(int32_t));
+  b.count = (int32_t*)take(1024 * sizeof(int32_t));
+  b.tile_off = (int32_t*)take(1024 * sizeof(int32_t));
+  b.cursor = (int32_t*)take(1024 * sizeof(int32_t));
+  b.n_work = (int32_t*)take(sizeof(int32_t));
+  b.work = (int2*)take((nvt + M / 32 + 1) * sizeof(int2));
+  b.order = (int32_t*)take((size_t)M * sizeof(int32_t));
+  return off;
+}
+
+struct SelectParams {
+  FusedBufs b; int n_vtile; int tpl; int M;
+  const float* u; const int64_t* u_off; int64_t u_add;
+};
+
+// 16 lanes x 4 rows per wave: lane (q, rr) owns tiles [q*tpl, (q+1)*tpl) of row 4*wave_id + rr, so every
+// load instruction touches 32-byte sectors that are fully used.
+template <int TPL>
+__global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 2, rr = lane & 3;
+  const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + rr;
+  const bool ok = r < p.M;
+  const int rc = ok ? r : p.M - 1;
+  const int t0 = q * p.tpl;
+  float2 sv[TPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < TPL; ++i) {
+    const int t = t0 + i;
+    const bool valid = i < p.tpl && t < p.n_vtile;
+    sv[i] = valid ? p.b.stats[(int64_t)t * p.M + rc] : make_float2(-INFINITY, 0.f);
+    mx = fmaxf(mx, sv[i].x);
+  }
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  double sum = 0.0;
+#pragma unroll
+  for (int i = 0; i < TPL; ++i) sum += (double)sv[i].y * (double)fexp(sv[i].x - mx);
+  double incl = sum;
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {
+    const double t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  double excl = __shfl_up(incl, 4, 64);
+  if (q == 0) excl = 0.0;
+  const double total = __shfl(incl, 60 + rr, 64);
+  const double target = (double)p.u[(p.u_off ? p.u_off[rc] : (int64_t)rc) + p.u_add] * total;
+  const unsigned long long bal = __ballot(incl > target) & (0x1111111111111111ull << rr);
+  const int last = p.n_vtile - 1;
+  const bool mine = bal ? (lane == __ffsll((long long)bal) - 1) : (t0 <= last && last < t0 + p.tpl);
+  if (!mine || !ok) return;
+  double run = excl, pre = excl, c_last = 0.0;
+  int sel = -1;
+#pragma unroll
+  for (int i = 0; i < TPL; ++i) {
+    const double c = (double)sv[i].y * (double)fexp(sv[i].x - mx);
+    if (sel < 0 && i < p.tpl && t0 + i < p.n_vtile) {
+      if (run + c > target) { sel = t0 + i; pre = run; }
+      else { run += c; c_last = c; }
+    }
+  }
+  if (sel < 0) { sel = last; pre = run - c_last; }      // u * total not below the final CDF value: last tile
+  p.b.sel_tile[r] = sel;
+  p.b.sel_max[r] = mx;
+  p.b.sel_pre[r] = pre;
+  p.b.sel_target[r] = target;
+  atomicAdd(&p.b.count[sel], 1);
+}
+
+// one 1024-thread block: exclusive scans of rows per tile and of 32-row chunks per tile
+__global__ __launch_bounds__(1024) void worklist_kernel(FusedBufs b, int n_vtile) {
+  __shared__ int s_c[1024], s_k[1024];
+  const int t = threadIdx.x;
+  const int c = t < n_vtile ? b.count[t] : 0;
+  const int k = (c + 31) >> 5;
+  s_c[t] = c; s_k[t] = k;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int ac = t >= o ? s_c[t - o] : 0, ak = t >= o ? s_k[t - o] : 0;
+    __syncthreads();
+    s_c[t] += ac; s_k[t] += ak;
+    __syncthreads();
+  }
+  if (t < n_vtile) {
+    b.tile_off[t] = s_c[t] - c;
+    b.cursor[t] = 0;
+    const int w0 = s_k[t] - k;
+    for (int j = 0; j < k; ++j) b.work[w0 + j] = make_int2(t, j);
+  }
+  if (t == 1023) *b.n_work = s_k[t];
+}
+
+__global__ __launch_bounds__(256) void scatter_kernel(FusedBufs b, int M) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= M) return;
+  const int t = b.sel_tile[r];
+  b.order[b.tile_off[t] + atomicAdd(&b.cursor[t], 1)] = r;
+}
+
+struct RecomputeParams {
+  FusedBufs b; const void* x; const void* w; int d; int V; int32_t* out;
+};
+
+template <typename OpT>
+__global__ __launch_bounds__(256) void recompute_kernel(RecomputeParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= *p.b.n_work) return;
+  const int2 wk = p.b.work[wid];
+  const int tile = wk.x;
+  const int nrow = min(32, p.b.count[tile] - 32 * wk.y);
+  const int n = lane & 31, h2 = lane >> 5;
+  const int row = p.b.order[p.b.tile_off[tile] + 32 * wk.y + min(n, nrow - 1)];
+  const int d = p.d;
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  if constexpr (sizeof(OpT) == 2) {
+    // S^T[vocab, row]: A = table rows (lane = vocab entry n of the 32-tile), B = hidden rows; k = 8*h2 + j
+    const bf16_t* wa = reinterpret_cast<const bf16_t*>(p.w) + ((int64_t)tile * 64 + n) * d + 8 * h2;
+    const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x) + (int64_t)row * d + 8 * h2;
+    for (int k1 = 0; k1 < d; k1 += 64)            // d * 2 bytes is a multiple of 128
+#pragma unroll
+    for (int k0 = k1; k0 < k1 + 64; k0 += 16) {
+      const uint4 a0 = *reinterpret_cast<const uint4*>(wa + k0);
+      const uint4 a1 = *reinterpret_cast<const uint4*>(wa + (int64_t)32 * d + k0);
+      const uint4 bb = *reinterpret_cast<const uint4*>(xb + k0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bb),
+                                                       acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bb),
+                                                       acc[1], 0, 0, 0);
+    }
+  } else {
+    // fp32 MFMA takes k = h2 per instruction; a 16-byte load per lane feeds 4 of them (k permuted the
+    // same way for both operands, which leaves every dot product unchanged)
+    const float* wa = reinterpret_cast<const float*>(p.w) + ((int64_t)tile * 64 + n) * d + 4 * h2;
+    const float* xb = reinterpret_cast<const float*>(p.x) + (int64_t)row * d + 4 * h2;
+    for (int k1 = 0; k1 < d; k1 += 32)            // d * 4 bytes is a multiple of 128
+#pragma unroll
+    for (int k0 = k1; k0 < k1 + 32; k0 += 8) {
+      const float4 a0 = *reinterpret_cast<const float4*>(wa + k0);
+      const float4 a1 = *reinterpret_cast<const float4*>(wa + (int64_t)32 * d + k0);
+      const float4 bb = *reinterpret_cast<const float4*>(xb + k0);
+      const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], bv[i], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], bv[i], acc[1], 0, 0, 0);
+      }
+    }
+  }
+  // this lane: query row n; acc[t][e] = logit of tile entry 32t + 8(e>>2) + 4*h2 + (e&3)
+  const float mx = p.b.sel_max[row];
+  const double target = p.b.sel_target[row];
+  float ev[2][16];
+  double qs[2][4], pq[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ev[t][4 * g + j] = fexp(acc[t][4 * g + j] - mx);
+        s += (double)ev[t][4 * g + j];
+      }
+      qs[t][g] = s;
+      pq[t][g] = __shfl_xor(s, 32, 64);
+    }
+  // both half-waves walk the 16 quads of 4 consecutive entries in vocabulary order
+  double run = p.b.sel_pre[row];
+  bool found = false;
+  int token = -1;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const double s = hh == h2 ? qs[t][g] : pq[t][g];
+        if (!found) {
+          if (run + s > target) {
+            found = true;
+            if (hh == h2) {
+              double r2 = run;
+              int j3 = 3;
+              bool f2 = false;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                r2 += (double)ev[t][4 * g + j];
+                if (!f2 && r2 > target) { f2 = true; j3 = j; }
+              }
+              token = 32 * t + 8 * g + 4 * hh + j3;
+            }
+          } else {
+            run += s;
+          }
+        }
+      }
+  if (!found && h2 == 1) token = 63;
+  if (token >= 0 && n < nrow) p.out[row] = min(tile * 64 + token, p.V - 1);
+}
+
+size_t logits_sample_workspace(int M, int V) {
+  FusedBufs b;
+  return carve_fused(nullptr, M, V, b);
+}
+
+int launch_logits_sample(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
+                         const int64_t* u_off, int64_t u_add, int32_t* out, void* ws, hipStream_t st) {
+  if (M == 0) return 0;
+  NMTGAN_REQUIRE(x && w && u && out && ws && M > 0, "logits_sample: bad arguments");
+  NMTGAN_REQUIRE(gemm_stats_supported(op_dtype, V, d), "logits_sample: unsupported shape V=%d d=%d", V, d);
+  const int nvt = V / 64;
+  FusedBufs b;
+  carve_fused((char*)ws, M, V, b);
+  NMTGAN_TRY(launch_gemm_stats(op_dtype, w, V, x, M, d, b.stats, st));
+  prof::Scope prof_scope(prof::SAMPLER, st);
+  if (hipMemsetAsync(b.count, 0, 1024 * sizeof(int32_t), st) != hipSuccess) NMTGAN_FAIL(-3, "logits_sample: memset failed");
+  const int tpl = (nvt + 15) / 16;
+  SelectParams sp{b, nvt, tpl, M, u, u_off, u_add};
+  const dim3 sgrid((M + 15) / 16);
+  if (tpl <= 8) hipLaunchKernelGGL(select_kernel<8>, sgrid, dim3(256), 0, st, sp);
+  else if (tpl <= 32) hipLaunchKernelGGL(select_kernel<32>, sgrid, dim3(256), 0, st, sp);
+  else hipLaunchKernelGGL(select_kernel<64>, sgrid, dim3(256), 0, st, sp);
+  NMTGAN_CHECK_LAUNCH("sample_select");
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, st, b, nvt);
+  NMTGAN_CHECK_LAUNCH("sample_worklist");
+  hipLaunchKernelGGL(scatter_kernel, dim3((M + 255) / 256), dim3(256), 0, st, b, M);
+  NMTGAN_CHECK_LAUNCH("sample_scatter");
+  RecomputeParams rp{b, x, w, d, V, out};
+  const dim3 rgrid((nvt + M / 32 + 1 + 3) / 4);
+  if (op_dtype == NMTGAN_BF16) hipLaunchKernelGGL(recompute_kernel<bf16_t>, rgrid, dim3(256), 0, st, rp);
+  else hipLaunchKernelGGL(recompute_kernel<float>, rgrid, dim3(256), 0, st, rp);
+  NMTGAN_CHECK_LAUNCH("sample_recompute");
+  return 0;
+}
+
+}  // namespace nmtgan
