@@ -75,7 +75,9 @@ def algorithmic_work(cfg, plan, B, Ls, es):
         "gemm_logits": ("mfma", 2 * d * V * dec_rows),
         "gemm_conv": ("mfma", conv_per_row * scored),
         "gemm_highway": ("mfma", 4 * F * F * scored),
-        "sampler": ("hbm", (plan.n_rows + step_rows) * (4 * V + 8)),
+        # first token of every rollout: a shared prefix-logits row; rollout steps (fused path): the
+        # per-tile stats row (8 B per 64 vocabulary entries), the hidden state and the bookkeeping words
+        "sampler": ("hbm", plan.n_rows * (4 * V + 8) + step_rows * (8 * V // 64 + d * es + 40)),
         "attn_self_step": ("hbm", N * kv_entry * self_entries),
         "attn_cross_step": ("hbm", N * kv_entry * cross_entries),
     }
