@@ -295,6 +295,9 @@ typedef struct {
   float* p_rows;                    /* out [n_rows] P(real) per rollout, may be NULL */
   float* p_base;                    /* out [B] P(real) of y_sample itself, may be NULL */
   float* prefix_logits;             /* out [B][T][V] teacher-forced logits, may be NULL */
+  const int32_t* row_g_host;        /* HOST copy of row_g, may be NULL.  When given, the discriminator skips
+                                       the conv windows that end inside a rollout's given prefix (same value
+                                       as in y_sample) and takes their max from one pass over y_sample */
 } nmtgan_reward_plan;
 size_t nmtgan_rollout_reward_workspace_bytes(const nmtgan_generator* g, const nmtgan_discriminator* d,
                                              const nmtgan_reward_plan* plan);

@@ -100,7 +100,8 @@ class RewardPlan(C.Structure):
                 ("row_b", vp), ("row_g", vp), ("row_gp1", vp), ("row_lrow", vp), ("row_uoff", vp),
                 ("grp_first", vp), ("uniforms", vp), ("use_bias", i32), ("bias_num", f64),
                 ("logits_chunk_rows", i32), ("disc_chunk_rows", i32),
-                ("rewards", vp), ("rollouts", vp), ("p_rows", vp), ("p_base", vp), ("prefix_logits", vp)]
+                ("rewards", vp), ("rollouts", vp), ("p_rows", vp), ("p_base", vp), ("prefix_logits", vp),
+                ("row_g_host", vp)]
 
 
 EXPORTS = {

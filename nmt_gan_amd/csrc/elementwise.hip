@@ -182,6 +182,57 @@ int launch_cast_rows(const float* in, void* out, int op_dtype, int64_t n, hipStr
   return 0;
 }
 
+// Prefix-window reuse in the discriminator (the rollouts of (b, g) share tokens 0..g-1 with y_sample[b], so
+// every conv window that ends inside the prefix has the same value as in y_sample):
+// C[b*T + p][col] holds relu(bn(conv)) of window p of y_sample[b]; pm[b*T + g][col] = max over p <= g - w(col).
+struct WidthTable { int n; int col_end[NMTGAN_MAX_WIDTHS]; int width[NMTGAN_MAX_WIDTHS]; };
+__global__ void prefix_max_kernel(const float* C, float* pm, int B, int T, int Fp, WidthTable wt) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (col >= Fp) return;
+  int w = T + 1;                                   // padding columns: never any window
+  for (int i = 0; i < wt.n; ++i)
+    if (col < wt.col_end[i]) { w = wt.width[i]; break; }
+  float run = 0.f;                                 // ReLU floor: the neutral element of the max-pool here
+  for (int g = 0; g < T; ++g) {
+    if (g - w >= 0) run = fmaxf(run, C[((int64_t)b * T + g - w) * Fp + col]);
+    pm[((int64_t)b * T + g) * Fp + col] = run;
+  }
+}
+int launch_prefix_max(const float* C, float* pm, int B, int T, int Fp, int n_widths, const int* widths,
+                      const int* n_filters, hipStream_t st) {
+  prof::Scope prof_scope(prof::DISC_SMALL, st);
+  NMTGAN_REQUIRE(C && pm && B > 0 && T > 0 && Fp > 0 && n_widths > 0 && n_widths <= NMTGAN_MAX_WIDTHS,
+                 "prefix_max: bad arguments");
+  WidthTable wt{};
+  wt.n = n_widths;
+  int col = 0;
+  for (int i = 0; i < n_widths; ++i) { col += n_filters[i]; wt.col_end[i] = col; wt.width[i] = widths[i]; }
+  hipLaunchKernelGGL(prefix_max_kernel, dim3((Fp + 255) / 256, B), dim3(256), 0, st, C, pm, B, T, Fp, wt);
+  NMTGAN_CHECK_LAUNCH("prefix_max");
+  return 0;
+}
+
+// pooled[i][:] = pm[row_b[i]*T + row_g[i]][:]
+__global__ void pool_init_kernel(const float* pm, const int32_t* row_b, const int32_t* row_g, int T, int Fp4,
+                                 int64_t n4, float4* pooled) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int r = (int)(i / Fp4), c = (int)(i % Fp4);
+  pooled[i] = reinterpret_cast<const float4*>(pm)[((int64_t)row_b[r] * T + row_g[r]) * Fp4 + c];
+}
+int launch_pool_init(const float* pm, const int32_t* row_b, const int32_t* row_g, int rows, int T, int Fp,
+                     float* pooled, hipStream_t st) {
+  prof::Scope prof_scope(prof::DISC_SMALL, st);
+  if (rows == 0) return 0;
+  NMTGAN_REQUIRE(pm && row_b && row_g && pooled && Fp % 4 == 0, "pool_init: bad arguments");
+  const int64_t n4 = (int64_t)rows * (Fp / 4);
+  hipLaunchKernelGGL(pool_init_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, pm, row_b, row_g, T,
+                     Fp / 4, n4, (float4*)pooled);
+  NMTGAN_CHECK_LAUNCH("pool_init");
+  return 0;
+}
+
 // highway (cnn_discriminator.py:50-59, layer_size 1, bias 0): out = sig(t)*relu(o) + (1-sig(t))*H
 __global__ void highway_gate_kernel(const float* H, const float* o, const float* t, float* out, int64_t n) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;

@@ -28,6 +28,10 @@ int launch_scatter_tokens(const int32_t* tok, const int32_t* row_g, int add, int
 int launch_disc_embed(const void* table, int op_dtype, int vocab, const int32_t* ids, int64_t n_tok, int E,
                       void* out, hipStream_t st);
 int launch_cast_rows(const float* in, void* out, int op_dtype, int64_t n, hipStream_t st);
+int launch_prefix_max(const float* C, float* pm, int B, int T, int Fp, int n_widths, const int* widths,
+                      const int* n_filters, hipStream_t st);
+int launch_pool_init(const float* pm, const int32_t* row_b, const int32_t* row_g, int rows, int T, int Fp,
+                     float* pooled, hipStream_t st);
 int launch_highway_gate(const float* H, const float* o, const float* t, float* out, int64_t n, hipStream_t st);
 int launch_disc_head(const float* feat_t, const float* feat_s, const int32_t* src_row, int M, int Fp,
                      const float* head_w, const float* head_b, float* p_real, float* probs2, hipStream_t st);

@@ -257,23 +257,48 @@ static void carve_disc(Arena& ar, const nmtgan_discriminator* d, int chunk, Disc
   b.ht = ar.get<float>((int64_t)chunk * d->Fp);
 }
 
+// Windows a rollout shares with y_sample (those ending inside its given prefix) are not recomputed: their
+// max comes from pm[b*T + g][Fp] (prefix_max over one pass on y_sample); g_min = smallest give_num of the chunk.
+struct PrefixReuse { const float* pm; const int32_t* row_b; const int32_t* row_g; const int32_t* row_g_host; };
+static const int REUSE_ROWS = [] { const char* e = getenv("NMTGAN_REUSE_ROWS"); return e && atoi(e) > 0 ? atoi(e) : 4096; }();   // granularity at which the first computed window is chosen
+
 // highway features of `rows` sentences ids[rows][T] -> feat[rows][Fp]
 static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* ids,
-                               int rows, float* feat, DiscBufs& b, hipStream_t st) {
+                               int rows, float* feat, DiscBufs& b, hipStream_t st, const PrefixReuse* reuse = nullptr) {
   const int T = d->max_len, E = d->dim_word, Fp = d->Fp, op = d->op_dtype;
   NMTGAN_TRY(launch_disc_embed(tw.emb, op, &tw == &d->src ? d->vocab_s : d->vocab, ids, (int64_t)rows * T, E, b.e, st));
-  if (hipMemsetAsync(b.pooled, 0, (size_t)rows * Fp * sizeof(float), st) != hipSuccess)
+  if (reuse) {
+    NMTGAN_TRY(launch_pool_init(reuse->pm, reuse->row_b, reuse->row_g, rows, T, Fp, b.pooled, st));
+  } else if (hipMemsetAsync(b.pooled, 0, (size_t)rows * Fp * sizeof(float), st) != hipSuccess) {
     NMTGAN_FAIL(-3, "disc: memset failed");
+  }
   int col = 0;
   for (int i = 0; i < d->n_widths; ++i) {
-    const int w = d->widths[i], P = T - w + 1;
-    nmtgan_gemm_args a{};
-    a.op_dtype = op; a.epilogue = NMTGAN_EPI_CONVMAX;
-    a.A = b.e; a.Wt = tw.conv_w[i]; a.M = rows * P; a.N = d->n_filters[i]; a.K = w * E;
-    a.lda = E; a.a_group = P; a.a_group_stride = (int64_t)T * E;
-    a.scale = tw.conv_scale[i]; a.shift = tw.conv_shift[i]; a.pooled = b.pooled + col; a.ld_pool = Fp;
-    prof::Hint ph(prof::GEMM_CONV);
-    NMTGAN_TRY(launch_gemm(&a, st));
+    const int w = d->widths[i];
+    // sub-ranges of REUSE_ROWS rows; p0 = first window that can contain a sampled token of any row of the
+    // sub-range (p + w > smallest give_num); neighbours with the same p0 are merged into one GEMM
+    for (int s0 = 0; s0 < rows;) {
+      auto first_window = [&](int lo) {
+        if (!reuse) return 0;
+        int g_min = T;
+        for (int r = lo; r < rows && r < lo + REUSE_ROWS; ++r) g_min = reuse->row_g_host[r] < g_min ? reuse->row_g_host[r] : g_min;
+        return g_min - w + 1 > 0 ? g_min - w + 1 : 0;
+      };
+      const int p0 = first_window(s0);
+      int s1 = s0 + REUSE_ROWS < rows ? s0 + REUSE_ROWS : rows;
+      if (!reuse) s1 = rows;
+      while (s1 < rows && first_window(s1) == p0) s1 = s1 + REUSE_ROWS < rows ? s1 + REUSE_ROWS : rows;
+      const int P = T - w + 1 - p0;
+      nmtgan_gemm_args a{};
+      a.op_dtype = op; a.epilogue = NMTGAN_EPI_CONVMAX;
+      a.A = at(b.e, ((int64_t)s0 * T + p0) * E, dtype_size(op)); a.Wt = tw.conv_w[i];
+      a.M = (s1 - s0) * P; a.N = d->n_filters[i]; a.K = w * E;
+      a.lda = E; a.a_group = P; a.a_group_stride = (int64_t)T * E;
+      a.scale = tw.conv_scale[i]; a.shift = tw.conv_shift[i]; a.pooled = b.pooled + (int64_t)s0 * Fp + col; a.ld_pool = Fp;
+      prof::Hint ph(prof::GEMM_CONV);
+      NMTGAN_TRY(launch_gemm(&a, st));
+      s0 = s1;
+    }
     col += d->n_filters[i];
   }
   NMTGAN_TRY(launch_cast_rows(b.pooled, b.pooled_op, op, (int64_t)rows * Fp, st));
@@ -284,6 +309,29 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
     NMTGAN_TRY(dense1(op, b.pooled_op, Fp, rows, Fp, Fp, wt, b.ht, Fp, 1, 1.f, 0, st));
   }
   return launch_highway_gate(b.pooled, b.ho, b.ht, feat, (int64_t)rows * Fp, st);
+}
+
+// C[b*T + p][Fp] = relu(bn(conv)) of every window p of rows sentences (one "sentence" of rows*T tokens with
+// a pooling group of one window; windows that run over a sentence end are computed and never read)
+static int disc_window_values(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* ids, int rows,
+                              float* Cw, DiscBufs& b, hipStream_t st) {
+  const int T = d->max_len, E = d->dim_word, Fp = d->Fp, op = d->op_dtype;
+  NMTGAN_TRY(launch_disc_embed(tw.emb, op, d->vocab, ids, (int64_t)rows * T, E, b.e, st));
+  if (hipMemsetAsync(Cw, 0, (size_t)rows * T * Fp * sizeof(float), st) != hipSuccess)
+    NMTGAN_FAIL(-3, "disc: memset failed");
+  int col = 0;
+  for (int i = 0; i < d->n_widths; ++i) {
+    const int w = d->widths[i];
+    nmtgan_gemm_args a{};
+    a.op_dtype = op; a.epilogue = NMTGAN_EPI_CONVMAX;
+    a.A = b.e; a.Wt = tw.conv_w[i]; a.M = rows * T - w + 1; a.N = d->n_filters[i]; a.K = w * E;
+    a.lda = E; a.a_group = 1; a.a_group_stride = E;
+    a.scale = tw.conv_scale[i]; a.shift = tw.conv_shift[i]; a.pooled = Cw + col; a.ld_pool = Fp;
+    prof::Hint ph(prof::GEMM_CONV);
+    NMTGAN_TRY(launch_gemm(&a, st));
+    col += d->n_filters[i];
+  }
+  return 0;
 }
 
 int disc_workspace(const nmtgan_discriminator* d, int chunk, size_t* bytes) {
@@ -321,6 +369,7 @@ struct RewardBufs {
   void* fused_ws; bool fused;                 // logits never materialised during the rollout steps
   int32_t* Y; int32_t* tok_cur;
   float *feat_s, *feat_t, *p_rows, *p_base;
+  float *win_vals, *win_pm; bool reuse;        // prefix-window reuse in the discriminator
   DiscBufs disc;
   int64_t act_rows, logits_rows, pr_rows;
   int disc_chunk;
@@ -370,7 +419,7 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   b.prefix_logits = p->prefix_logits ? p->prefix_logits : ar.get<float>(pre_rows * g->vocab_dst);
   b.Y = p->rollouts ? p->rollouts : ar.get<int32_t>((int64_t)(p->n_rows > 0 ? p->n_rows : 1) * p->T);
   b.tok_cur = ar.get<int32_t>(p->n_rows > 0 ? p->n_rows : 1);
-  b.disc_chunk = p->disc_chunk_rows > 0 ? p->disc_chunk_rows : 4096;
+  b.disc_chunk = p->disc_chunk_rows > 0 ? p->disc_chunk_rows : 8192;
   const int64_t most = p->n_rows > p->B ? p->n_rows : p->B;
   if (b.disc_chunk > most) b.disc_chunk = (int)most;
   b.feat_s = ar.get<float>((int64_t)p->B * d->Fp);
@@ -378,6 +427,14 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   b.p_rows = p->p_rows ? p->p_rows : ar.get<float>(p->n_rows > 0 ? p->n_rows : 1);
   b.p_base = p->p_base ? p->p_base : ar.get<float>(p->B);
   carve_disc(ar, d, b.disc_chunk, b.disc);
+  static const bool reuse_env = [] { const char* e = getenv("NMTGAN_CONV_REUSE"); return !e || atoi(e) != 0; }();
+  b.reuse = reuse_env && p->row_g_host != nullptr && p->n_rows > 0;
+  b.win_vals = b.win_pm = nullptr;
+  if (b.reuse) {
+    const int64_t wrows = (int64_t)(p->B < b.disc_chunk ? p->B : b.disc_chunk) * p->T;
+    b.win_vals = ar.get<float>(wrows * d->Fp);
+    b.win_pm = ar.get<float>((int64_t)p->B * p->T * d->Fp);
+  }
   return 0;
 }
 
@@ -496,9 +553,18 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
     NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s + (int64_t)r0 * d->Fp, nullptr, rows, d->Fp, d->head_w, d->head_b,
                                 b.p_base + r0, nullptr, st));
   }
+  if (b.reuse) {
+    for (int r0 = 0; r0 < B; r0 += b.disc_chunk) {
+      const int rows = B - r0 < b.disc_chunk ? B - r0 : b.disc_chunk;
+      NMTGAN_TRY(disc_window_values(d, d->tgt, p->y + (int64_t)r0 * T, rows, b.win_vals, b.disc, st));
+      NMTGAN_TRY(launch_prefix_max(b.win_vals, b.win_pm + (int64_t)r0 * T * d->Fp, rows, T, d->Fp, d->n_widths, d->widths,
+                                   d->n_filters, st));
+    }
+  }
   for (int r0 = 0; r0 < p->n_rows; r0 += b.disc_chunk) {
     const int rows = p->n_rows - r0 < b.disc_chunk ? p->n_rows - r0 : b.disc_chunk;
-    NMTGAN_TRY(disc_features_chunk(d, d->tgt, b.Y + (int64_t)r0 * T, rows, b.feat_t, b.disc, st));
+    PrefixReuse pr{b.win_pm, p->row_b + r0, p->row_g + r0, b.reuse ? p->row_g_host + r0 : nullptr};
+    NMTGAN_TRY(disc_features_chunk(d, d->tgt, b.Y + (int64_t)r0 * T, rows, b.feat_t, b.disc, st, b.reuse ? &pr : nullptr));
     NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s, p->row_b + r0, rows, d->Fp, d->head_w, d->head_b, b.p_rows + r0,
                                 nullptr, st));
   }

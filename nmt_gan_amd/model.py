@@ -70,7 +70,7 @@ class Model(object):
         self._keep, self._c = [], None
         self._ws = None
         self.logits_chunk_rows = 4096
-        self.disc_chunk_rows = 4096
+        self.disc_chunk_rows = 8192
         self.last_details = None
 
     # ------------------------------------------------------------------ graph-building surface
@@ -308,12 +308,14 @@ class Model(object):
         }
         live = np.ascontiguousarray(plan.live, dtype=np.int32)
         step_off_h = np.ascontiguousarray(plan.step_off, dtype=np.int64)
+        row_g_h = np.ascontiguousarray(plan.row_g, dtype=np.int32)
         p = _lib.RewardPlan()
         p.B, p.Ls, p.T, p.rollnum = B, Ls, T, int(rollnum)
         p.n_rows, p.n_steps = plan.n_rows, plan.n_steps
         p.live = live.ctypes.data
         p.step_off_host = step_off_h.ctypes.data
         p.step_off = ptr(t["step_off"])
+        p.row_g_host = row_g_h.ctypes.data if plan.n_rows > 0 else None
         p.x, p.x_pad, p.x_pad_to_T = ptr(t["x"]), ptr(t["x_pad"]), ptr(t["x_pad_T"])
         p.y, p.dec_in, p.mask = ptr(t["y"]), ptr(t["dec_in"]), ptr(t["mask"])
         p.row_b, p.row_g, p.row_gp1 = ptr(t["row_b"]), ptr(t["row_g"]), ptr(t["row_gp1"])
@@ -338,7 +340,7 @@ class Model(object):
         g, dsc = self.c_struct, disc.c_struct
         need = lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(dsc), C.byref(p))
         ws = self._workspace(need)
-        return PreparedReward(self, disc, plan, p, t, (live, step_off_h), ws, details)
+        return PreparedReward(self, disc, plan, p, t, (live, step_off_h, row_g_h), ws, details)
 
     def get_reward_Obinforced(self, *a, **k):
         raise NotImplementedError("get_reward_Obinforced is never called by the reference drivers (SURVEY section 2 #5)")

@@ -123,6 +123,16 @@ def test_get_reward_fp32_matches_oracle(cuda, d, heads):
     assert np.all(r[4] == 0)
 
 
+def test_get_reward_small_chunks_fp32(cuda, setup):
+    """Chunk boundaries of the discriminator (prefix-window reuse takes the smallest give_num of each
+    chunk) and of the unfused logits/sampler loop do not change the result."""
+    s = setup
+    m, disc = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], "fp32", T)
+    m.disc_chunk_rows, m.logits_chunk_rows = 3, 5
+    r = m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, disc, max_len=T, bias_num=0.6, uniforms=s["u"])
+    assert np.abs(r - s["ref_r"]).max() < 1e-5 * max(1.0, np.abs(s["ref_r"]).max())
+
+
 def test_get_reward_no_bias_fp32(cuda, setup):
     s = setup
     r, _ = _gpu_reward(s, "fp32", bias_num=None)
