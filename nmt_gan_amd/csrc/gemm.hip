@@ -21,6 +21,8 @@
 // GROUP_M row panels of A stay L2-resident while the Wt tiles stream.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -66,6 +68,12 @@ __device__ __forceinline__ void mma_chunk<float>(const uint4& a, const uint4& b,
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
 }
 
+// element i of a 3-entry kernel-argument array WITHOUT dynamic indexing: an indexed access makes hipcc fetch
+// the argument with a vector load, and the vmcnt wait it places (inside the conditional store blocks) leaks
+// into the k-loops as a vmcnt(0) that drains the LDS-DMA pipeline every iteration
+template <typename T>
+__device__ __forceinline__ T pick3(const T (&a)[3], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
+
 // bijective XCD remap + grouped-M order -> (tile_m, tile_n)
 __device__ __forceinline__ void tile_index(const GemmParams& p, int& tm, int& tn) {
   const int nwg = p.ntm * p.ntn;
@@ -84,24 +92,27 @@ __device__ __forceinline__ int64_t a_row_offset(const GemmParams& p, int r) {
 }
 
 // Epilogue of one wave's 64x64 tile.  32x32 C layout: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
-template <typename OpT, int EPI>
-__device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int lane) {
+// ev: optional LDS copy of the wave's 64 per-column epilogue values ([64] bias, or [64] scale + [64] shift),
+// staged by LDS-DMA so that no compiler-visible vector load sits next to the hand-counted DMA stream
+template <typename OpT, int EPI, int MT = 2>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[MT][2], int m0, int n0, int lane,
+                                         const float* ev = nullptr) {
   const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + j * 32 + fr;
     if (n >= p.N) continue;
     if constexpr (EPI == NMTGAN_EPI_LINEAR) {
-      const float bias = p.bias ? p.bias[n] : 0.f;
+      const float bias = ev ? ev[j * 32 + fr] : (p.bias ? p.bias[n] : 0.f);
       const int seg = (p.n_seg > 1) ? n / p.seg_width : 0;
       const int nn = (p.n_seg > 1) ? n - seg * p.seg_width : n;
-      const float sc = p.seg_scale[seg];
-      const int64_t ldo = p.ldo[seg];
-      const bool of32 = p.out_f32[seg] != 0;
-      float* of = reinterpret_cast<float*>(p.out[seg]);
-      OpT* oo = reinterpret_cast<OpT*>(p.out[seg]);
+      const float sc = pick3(p.seg_scale, seg);
+      const int64_t ldo = pick3(p.ldo, seg);
+      const bool of32 = pick3(p.out_f32, seg) != 0;
+      float* of = reinterpret_cast<float*>(pick3(p.out, seg));
+      OpT* oo = reinterpret_cast<OpT*>(pick3(p.out, seg));
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
@@ -114,11 +125,11 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[2][2
         }
       }
     } else {
-      const float sc = p.scale[n], sh = p.shift[n];
+      const float sc = ev ? ev[j * 32 + fr] : p.scale[n], sh = ev ? ev[64 + j * 32 + fr] : p.shift[n];
       int cur_g = -1;
       float cur_v = 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
@@ -238,22 +249,31 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
 // LINEAR epilogue with 16-byte stores: each 16x32 accumulator chunk is transposed through a 2 KiB
 // per-wave LDS scratch so that a store instruction writes whole 128-byte (fp32) / 64-byte (bf16) row
 // segments: 16 (fp32) or 8 (bf16) store instructions per wave tile instead of 64 scalar ones.
 // Needs N % 64 == 0, segment widths % 64 == 0 and 16-byte aligned output rows (checked at launch).
-template <typename OpT>
-__device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int lane,
-                                              float* scr, bool f32_out, int seg, int nn0) {
+template <typename OpT, int MT = 2>
+__device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x16 (&acc)[MT][2], int m0, int n0, int lane,
+                                              float* scr, bool f32_out, int seg, int nn0, const float* ev = nullptr) {
   const int fr = lane & 31, fh = lane >> 5;
-  const float sc = p.seg_scale[seg];
-  const int64_t ldo = p.ldo[seg];
-  char* outp = reinterpret_cast<char*>(p.out[seg]);
+  const float sc = pick3(p.seg_scale, seg);
+  const int64_t ldo = pick3(p.ldo, seg);
+  char* outp = reinterpret_cast<char*>(pick3(p.out, seg));
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const float bias = p.bias ? p.bias[n0 + j * 32 + fr] : 0.f;
+    const float bias = ev ? ev[j * 32 + fr] : (p.bias ? p.bias[n0 + j * 32 + fr] : 0.f);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -289,25 +309,29 @@ __device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x16 (&acc)
 // the two half-waves: tile max and sum of exp(l - max) are in-lane reductions plus one cross-half
 // exchange.  stats[vtile][row] = (max, sum) with vtile = vocab/64; launch_logits_sample turns them
 // into a sampled token (sampler.hip).
-__device__ __forceinline__ void epilogue_stats(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int lane) {
-  if (m0 >= p.M) return;                           // vocab size is a multiple of 64: whole tile in or out
+template <int MT = 2>
+__device__ __forceinline__ void epilogue_stats(const GemmParams& p, f32x16 (&acc)[MT][2], int m0, int n0, int lane) {
   const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    float mx = -INFINITY;
+  for (int ip = 0; ip < MT / 2; ++ip) {
+    if (m0 + 64 * ip >= p.M) continue;             // vocab size is a multiple of 64: whole tile in or out
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+      float mx = -INFINITY;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[i][j][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
+      for (int i = 2 * ip; i < 2 * ip + 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[i][j][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f((acc[i][j][e] - mx) * 1.44269504088896341f);
-    sum += __shfl_xor(sum, 32, 64);
-    const int row = n0 + j * 32 + fr;
-    if (fh == 0 && row < p.N) p.stats[(int64_t)(m0 >> 6) * p.N + row] = make_float2(mx, sum);
+      for (int i = 2 * ip; i < 2 * ip + 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f((acc[i][j][e] - mx) * 1.44269504088896341f);
+      sum += __shfl_xor(sum, 32, 64);
+      const int row = n0 + j * 32 + fr;
+      if (fh == 0 && row < p.N) p.stats[(int64_t)((m0 >> 6) + ip) * p.N + row] = make_float2(mx, sum);
+    }
   }
 }
 
@@ -409,7 +433,7 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
       epilogue_stats(p, acc, m0, n0, lane);
     } else if (wide) {
       const int seg = (p.n_seg > 1) ? n0 / p.seg_width : 0;
-      const bool f32_out = p.out_f32[seg] != 0 || sizeof(OpT) == 4;
+      const bool f32_out = pick3(p.out_f32, seg) != 0 || sizeof(OpT) == 4;
       epilogue_wide<OpT>(p, acc, m0, n0, lane, scr, f32_out, seg, n0 - seg * p.seg_width);
       if (tm * PBM + PBM <= p.M) pend = f32_out ? 16 : 8;      // every store instruction was issued
     } else {
@@ -455,6 +479,278 @@ static int launch_pipe(GemmParams p, hipStream_t st) {
   if (const char* e = getenv("NMTGAN_GEMM_SMEM")) smem_use = atoi(e);
   hipLaunchKernelGGL((gemm_pipe_kernel<OpT, EPI>), dim3(grid), dim3(512), smem_use, st, p);
   NMTGAN_CHECK_LAUNCH("gemm_pipe");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ 256x256 kernel
+// Persistent 256x256 tile, 8 waves as 2 (M) x 4 (N), wave tile 128x64 = 4x2 MFMA tiles: per k-tile a wave
+// reads 24 KiB of LDS for 32 MFMAs (the 64x64 wave tile of gemm_pipe_kernel reads 16 KiB for 16, i.e. the
+// LDS read pipe is as busy as the matrix cores), and the block fetches 64 KiB per 8.4 MFLOP (48 per 4.2).
+// The k-tile is cut into four 16 KiB staging units - A0/A1 = the first/second 64 rows of every wave's
+// 128, B0/B1 = the first/second 32 columns of every wave's 64 - held twice (k parity): 128 KiB.
+// A k-step runs four phases, one C quadrant each:
+//     P1 (A0,B0)   P2 (A0,B1)   P3 (A1,B1)   P4 (A1,B0)
+// phase = [ds_read the operands this quadrant still lacks; issue one unit of LDS-DMA; counted vmcnt]
+//         s_barrier [8 MFMAs at raised priority] s_barrier
+// and the two wave groups (waves 0-3 / 4-7 = one wave per SIMD each) run ONE barrier apart, so on every
+// SIMD one wave feeds the matrix core while the other does its LDS reads and DMA issue.
+// Staging order A0(s+2)@P3 B0(s+2)@P4 B1(s+1)@P1 A1(s+1)@P2 keeps every unit >= 2 phases clear of its last
+// read (WAR) and gives it >= 5 phases to land; vmcnt(8) = the four youngest units may still be in flight,
+// placed in the phase BEFORE the one that reads the awaited unit (the other group reads it one barrier
+// later; guide section 5, "Read a staged buffer one phase AFTER the wait that retires it").
+constexpr int QBM = 256, QBN = 256, QUNIT = 128 * BKB, QSTAGE = 4 * QUNIT;
+
+// LDS-DMA without the m0 save/restore of glds16: m0 is declared clobbered instead (gfx950 DS instructions do
+// not read m0, so the compiler keeps nothing live in it around these)
+__device__ __forceinline__ void glds16_m0(const void* gsrc, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+}
+
+template <typename OpT, int EPI>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nwg = p.ntm * p.ntn;
+  const int G = gridDim.x;
+  const int nkt = p.kbytes / BKB;                // >= 4 (launch guarantees it)
+  const int my_tiles = (nwg - (int)blockIdx.x + G - 1) / G;
+
+  auto tile_of = [&](int L, int& tm, int& tn) {
+    const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+    const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    const int group_size = p.group_m * p.ntn;
+    const int first_m = (idx / group_size) * p.group_m;
+    const int gsz = min(p.ntm - first_m, p.group_m);
+    tm = first_m + (idx % group_size) % gsz;
+    tn = (idx % group_size) / gsz;
+  };
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
+
+  // ---- staging: unit u (0 A0, 1 A1, 2 B0, 3 B1), two DMA instructions per wave and unit
+  using U0 = std::integral_constant<int, 0>;
+  using U1 = std::integral_constant<int, 1>;
+  using U2 = std::integral_constant<int, 2>;
+  using U3 = std::integral_constant<int, 3>;
+  const char* src[4][2];
+  auto point = [&](auto U, int ord) {            // unit U's sources at k-tile 0 of the block's tile `ord`
+    constexpr int u = decltype(U)::value;
+    int tm, tn;
+    tile_of((int)blockIdx.x + ord * G, tm, tn);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rho = 8 * (wave + 8 * j) + (lane >> 3);
+      const int lc = (lane & 7) ^ ((rho >> 1) & 7);
+      if constexpr (u < 2) {
+        const int row = tm * QBM + (rho >> 6) * 128 + u * 64 + (rho & 63);
+        src[u][j] = p.A + a_row_offset(p, min(row, p.M - 1)) + lc * 16;
+      } else {
+        const int col = tn * QBN + (rho >> 5) * 64 + (u - 2) * 32 + (rho & 31);
+        src[u][j] = p.W + (int64_t)min(col, p.N - 1) * p.ldw_b + lc * 16;
+      }
+    }
+  };
+  auto issue = [&](auto U, int parity) {         // next k-tile of unit U into the stage of that parity
+    constexpr int u = decltype(U)::value;
+    const unsigned dst = lds_base + parity * QSTAGE + u * QUNIT + wave * 1024;
+    glds16_m0(src[u][0], dst);
+    glds16_m0(src[u][1], dst + 8 * 1024);
+    src[u][0] += BKB;
+    src[u][1] += BKB;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int fsw = (fr >> 1) & 7;
+  int pc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) pc[q] = ((2 * q + fh) ^ fsw) << 4;
+  const int a_rd = (wr * 64 + fr) * BKB;         // + h * QUNIT + i * 32 * BKB
+  const int b_rd = 2 * QUNIT + (wc * 32 + fr) * BKB;   // + h * QUNIT
+  float* scr = reinterpret_cast<float*>(smem + 2 * QSTAGE + wave * 2048);
+  // per-column epilogue values of the wave's 64 columns, LDS-DMA'd at the start of the tile's last k-step:
+  // they ride the same in-order vmcnt stream as the tile DMAs and the epilogue needs no vector load (which
+  // the compiler would wait vmcnt(0) for, draining the prefetch of the next tile)
+  constexpr int QEV = 2 * QSTAGE + 8 * 2048;
+  const float* ev = reinterpret_cast<const float*>(smem + QEV + wave * 512);
+  const bool use_ev = (EPI == NMTGAN_EPI_LINEAR && p.bias != nullptr) || EPI == NMTGAN_EPI_CONVMAX;
+  auto stage_ev = [&](int ord) {
+    int tm, tn;
+    tile_of((int)blockIdx.x + ord * G, tm, tn);
+    const int n = min(tn * QBN + wc * 64 + lane, p.N - 1);
+    const unsigned dst = lds_base + QEV + wave * 512;
+    if constexpr (EPI == NMTGAN_EPI_LINEAR) {
+      if (p.bias) glds4(p.bias + n, dst);
+    } else if constexpr (EPI == NMTGAN_EPI_CONVMAX) {
+      glds4(p.scale + n, dst);
+      glds4(p.shift + n, dst + 256);
+    }
+  };
+
+  uint4 fa[2][4], fb0[4], fb1[4];
+#define NMTGAN_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define NMTGAN_BAR()                       \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_s_barrier();          \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+  auto read_a = [&](const unsigned char* base, int h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        fa[i][q] = *reinterpret_cast<const uint4*>(base + h * QUNIT + a_rd + i * 32 * BKB + pc[q]);
+  };
+  auto read_b = [&](const unsigned char* base, int h, uint4 (&fb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fb[q] = *reinterpret_cast<const uint4*>(base + h * QUNIT + b_rd + pc[q]);
+  };
+  auto mfma8 = [&](auto H, auto HB, const uint4 (&fb)[4]) {
+    constexpr int h = decltype(H)::value, hb = decltype(HB)::value;
+    NMTGAN_BAR();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma_chunk<OpT>(fa[i][q], fb[q], acc[2 * h + i][hb]);
+    __builtin_amdgcn_s_setprio(0);
+    NMTGAN_BAR();
+  };
+
+  int par = 0;                                   // LDS stage of the current k-step
+  int t = 0;
+  // one k-step.  MODE 0: its stagings stay inside the tile; 1: k-tile nkt-2 (A0, B0 go to the next tile);
+  // 2: k-tile nkt-1 (all four go to the next tile).  Without a next tile the cross-tile stagings are
+  // skipped and the waits shrink to the units that are still in flight.
+  auto kstep = [&](auto MODE, bool has_next) {
+    constexpr int mode = decltype(MODE)::value;
+    const unsigned char* base = smem + par * QSTAGE;
+    if constexpr (mode == 2) stage_ev(t);
+    // P1: quadrant (A0, B0); stage B1 of the next k-step
+    read_b(base, 0, fb0);
+    read_a(base, 0);
+    if constexpr (mode == 2) {
+      if (has_next) { point(U3{}, t + 1); issue(U3{}, par ^ 1); }
+      if (has_next) NMTGAN_WAIT(8); else NMTGAN_WAIT(2);
+    } else {
+      issue(U3{}, par ^ 1);
+      NMTGAN_WAIT(8);                            // B1 of this k-step landed
+    }
+    mfma8(U0{}, U0{}, fb0);
+    // P2: quadrant (A0, B1); stage A1 of the next k-step
+    read_b(base, 1, fb1);
+    if constexpr (mode == 2) {
+      if (has_next) { point(U1{}, t + 1); issue(U1{}, par ^ 1); }
+      if (has_next) NMTGAN_WAIT(8); else NMTGAN_WAIT(0);
+    } else {
+      issue(U1{}, par ^ 1);
+      NMTGAN_WAIT(8);                            // A1 of this k-step landed
+    }
+    mfma8(U0{}, U1{}, fb1);
+    // P3: quadrant (A1, B1); stage A0 two k-steps ahead
+    read_a(base, 1);
+    if constexpr (mode == 0) {
+      issue(U0{}, par);
+    } else if (has_next) {
+      if constexpr (mode == 1) point(U0{}, t + 1);
+      issue(U0{}, par);
+    }
+    mfma8(U1{}, U1{}, fb1);
+    // P4: quadrant (A1, B0); stage B0 two k-steps ahead
+    if constexpr (mode == 0) {
+      issue(U2{}, par);
+      NMTGAN_WAIT(8);                            // A0, B0 of the next k-step landed
+    } else {
+      if (has_next) {
+        if constexpr (mode == 1) point(U2{}, t + 1);
+        issue(U2{}, par);
+        NMTGAN_WAIT(8);
+      } else if constexpr (mode == 1) {
+        NMTGAN_WAIT(4);
+      }
+    }
+    mfma8(U1{}, U0{}, fb0);
+    par ^= 1;
+  };
+  using M0 = std::integral_constant<int, 0>;
+  using M1 = std::integral_constant<int, 1>;
+  using M2 = std::integral_constant<int, 2>;
+
+  // prologue: A0 B0 B1 A1 of k-step 0, A0 B0 of k-step 1
+  point(U0{}, 0); point(U1{}, 0); point(U2{}, 0); point(U3{}, 0);
+  issue(U0{}, 0); issue(U2{}, 0); issue(U3{}, 0); issue(U1{}, 0); issue(U0{}, 1); issue(U2{}, 1);
+  NMTGAN_WAIT(8);
+  NMTGAN_BAR();
+  if (wr == 1) NMTGAN_BAR();                     // second wave group runs one barrier behind
+  for (; t < my_tiles; ++t) {
+    const bool has_next = t + 1 < my_tiles;
+    for (int kt = 0; kt < nkt - 2; ++kt) kstep(M0{}, true);
+    kstep(M1{}, has_next);
+    kstep(M2{}, has_next);
+    int tm, tn;
+    tile_of((int)blockIdx.x + t * G, tm, tn);
+    const int m0 = tm * QBM + wr * 128, n0 = tn * QBN + wc * 64;
+    bool wide = false;
+    if constexpr (EPI == NMTGAN_EPI_LINEAR) wide = p.wide_ok && n0 < p.N;
+    if constexpr (EPI == EPI_STATS) {
+      epilogue_stats<4>(p, acc, m0, n0, lane);
+    } else if (wide) {
+      const int seg = (p.n_seg > 1) ? n0 / p.seg_width : 0;
+      const bool f32_out = pick3(p.out_f32, seg) != 0 || sizeof(OpT) == 4;
+      epilogue_wide<OpT, 4>(p, acc, m0, n0, lane, scr, f32_out, seg, n0 - seg * p.seg_width, use_ev ? ev : nullptr);
+    } else {
+      epilogue<OpT, EPI, 4>(p, acc, m0, n0, lane, use_ev ? ev : nullptr);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  }
+  if (wr == 0) NMTGAN_BAR();                     // balance the barrier count of the two groups
+#undef NMTGAN_WAIT
+#undef NMTGAN_BAR
+}
+
+template <typename OpT, int EPI>
+static int launch_p8(GemmParams p, hipStream_t st) {
+  constexpr int smem = 2 * QSTAGE + 8 * 2048 + 8 * 512;   // 128 KiB of staging + per-wave epilogue scratch + vectors
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<OpT, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      NMTGAN_FAIL(-3, "gemm: cannot raise dynamic LDS limit");
+    attr_done = true;
+  }
+  p.ntm = (p.M + QBM - 1) / QBM;
+  p.ntn = (p.N + QBN - 1) / QBN;
+  p.group_m = 2;
+  if (const char* e = getenv("NMTGAN_GEMM_GM")) p.group_m = atoi(e);
+  if constexpr (EPI == NMTGAN_EPI_LINEAR) {
+    const int es = sizeof(OpT);
+    bool ok = p.N % 64 == 0 && (p.n_seg == 1 || p.seg_width % 64 == 0);
+    for (int s = 0; s < p.n_seg; ++s) {
+      const int oes = p.out_f32[s] ? 4 : es;
+      ok = ok && ((uintptr_t)p.out[s] % 16 == 0) && ((p.ldo[s] * oes) % 16 == 0);
+    }
+    p.wide_ok = ok ? 1 : 0;
+  }
+  const int nwg = p.ntm * p.ntn;
+  const int grid = nwg < 256 ? nwg : 256;
+  hipLaunchKernelGGL((gemm_p8_kernel<OpT, EPI>), dim3(grid), dim3(512), smem, st, p);
+  NMTGAN_CHECK_LAUNCH("gemm_p8");
   return 0;
 }
 
@@ -570,14 +866,50 @@ static int tile_override() {        // NMTGAN_GEMM_TILE=128|256|0(generic) for e
   return v;
 }
 
+// Kernel choice.  Both persistent kernels are power-limited on MI355X (the clock drops to ~1.5 GHz under
+// MFMA + LDS + DMA load), so the 256x256 kernel - fewer LDS and L2 bytes per flop - wins whenever its
+// larger tiles are not wasted on padding and the k-loop is long enough to amortise its epilogue.
+// Measured padded rates (bf16, random operands): ~1250 TFLOP/s for 256x256, ~1080 for 256x128.
+static int p8_mode() {              // NMTGAN_GEMM_P8=0 never, 1 heuristic (default), 2 always when legal
+  static const int v = [] { const char* e = getenv("NMTGAN_GEMM_P8"); return e ? atoi(e) : 1; }();
+  return v;
+}
+static bool prefer_p8(int64_t M, int N, int nkt) {
+  const int mode = p8_mode();
+  if (mode == 0 || nkt < 4) return false;
+  if (mode == 2) return true;
+  const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  if (tiles < 192) return false;
+  if (nkt < 16 && N < 2048) return false;        // K = 512 projections: the 256x128 kernel's store overlap wins
+  const double t_p8 = (double)((N + 255) / 256 * 256) / 1250.0, t_pipe = (double)((N + 127) / 128 * 128) / 1080.0;
+  return t_p8 < t_pipe;
+}
+
 template <typename OpT, int EPI>
 static int dispatch(const GemmParams& p, hipStream_t st) {
   const int ov = tile_override();
   if (p.kbytes % BKB != 0 || ov == 0) return launch_generic<OpT, EPI>(p, st);
-  // persistent pipelined 256x128 kernel when there are enough tiles to occupy the 256 CUs and the
-  // k-loop is long enough for its two-deep prefetch; else the simple double-buffered 128x128 kernel
+  // persistent pipelined kernels when there are enough tiles to occupy the 256 CUs and the k-loop is long
+  // enough for their two-deep prefetch; else the simple double-buffered 128x128 kernel
+  const int nkt = p.kbytes / BKB;
   const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 127) / 128);
-  const bool pipe_ok = p.kbytes / BKB >= 4;
+  const bool pipe_ok = nkt >= 4;
+  if constexpr (EPI == NMTGAN_EPI_CONVMAX) {
+    // filter counts are not multiples of 256: full 256-column panels on the 256x256 kernel, a remainder of
+    // <= 128 columns on the 256x128 kernel
+    const int rem = p.N % 256;
+    if (pipe_ok && p8_mode() == 1 && p.N > 256 && rem > 0 && rem <= 128 && nkt >= 16 &&
+        ((p.M + 255) / 256) * (int64_t)(p.N / 256) >= 192) {
+      GemmParams a = p, b = p;
+      a.N = p.N - rem;
+      b.N = rem;
+      b.W = p.W + (int64_t)a.N * p.ldw_b;
+      b.scale = p.scale + a.N; b.shift = p.shift + a.N; b.pooled = p.pooled + a.N;
+      NMTGAN_TRY((launch_p8<OpT, EPI>(a, st)));
+      return launch_pipe<OpT, EPI>(b, st);
+    }
+  }
+  if (pipe_ok && prefer_p8(p.M, p.N, nkt)) return launch_p8<OpT, EPI>(p, st);
   if (pipe_ok && (ov == 3 || (ov < 0 && tiles256 >= 192))) return launch_pipe<OpT, EPI>(p, st);
   if (ov == 256) return launch_glds<OpT, EPI, 256, 128>(p, st);
   return launch_glds<OpT, EPI, 128, 128>(p, st);
@@ -595,6 +927,9 @@ int launch_gemm_stats(int op_dtype, const void* W, int V, const void* X, int row
   p.M = V; p.N = rows; p.K = K;
   p.lda_b = (int64_t)K * es; p.ldw_b = (int64_t)K * es; p.kbytes = K * es;
   p.stats = stats;
+  static const bool stats_p8 = [] { const char* e = getenv("NMTGAN_STATS_P8"); return !e || atoi(e) != 0; }();
+  if (stats_p8 && prefer_p8(V, rows, p.kbytes / BKB))
+    return op_dtype == NMTGAN_BF16 ? launch_p8<bf16_t, EPI_STATS>(p, st) : launch_p8<float, EPI_STATS>(p, st);
   return op_dtype == NMTGAN_BF16 ? launch_pipe<bf16_t, EPI_STATS>(p, st) : launch_pipe<float, EPI_STATS>(p, st);
 }
 bool gemm_stats_supported(int op_dtype, int V, int K) {

@@ -66,6 +66,29 @@ def test_gemm_linear(cuda, op, M, N, K):
     assert err < tol, (err, tol)
 
 
+@pytest.mark.parametrize("op", ["bf16", "fp32"])
+@pytest.mark.parametrize("M,N,K,relu", [(10000, 2304, 768, 1), (70000, 512, 512, 0), (9000, 1300, 1024, 0)])
+def test_gemm_persistent_many_tiles(cuda, op, M, N, K, relu):
+    """Shapes with more output tiles than CUs: every workgroup of the persistent kernels walks several
+    tiles (cross-tile prefetch, epilogue under the next tile's loads, ragged last M/N tiles).  Checked in
+    full against a float64-accumulated torch product of the same operands."""
+    L = _lib()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dt = torch.bfloat16 if op == "bf16" else torch.float32
+    A = (torch.rand(M, K, generator=g) * 2 - 1).to(dt).to(cuda)
+    Wt = (torch.rand(N, K, generator=g) * 2 - 1 + torch.arange(N)[:, None] * 1e-4).to(dt).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    (out,) = _gemm(L, A, Wt, bias=bias, relu=relu, op=op)
+    worst = 0.0
+    for r0 in range(0, M, 4096):
+        ref = A[r0:r0 + 4096].double() @ Wt.double().T + bias.double()
+        if relu:
+            ref = torch.relu(ref)
+        worst = max(worst, (out[r0:r0 + 4096].double() - ref).abs().max().item())
+    tol = 2e-6 * K ** 0.5 * (K / 3) ** 0.5 + 1e-5
+    assert worst < tol, (worst, tol)
+
+
 def test_gemm_segments_and_scale(cuda):
     L = _lib()
     g = torch.Generator().manual_seed(3)
