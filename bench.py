@@ -83,6 +83,30 @@ def algorithmic_work(cfg, plan, B, Ls, es):
     }
 
 
+TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c2_bf16_hbm_traffic.json")
+# kernel classes -> kernels of the PMC summary (template argument 2 of the GEMM kernels is the epilogue)
+TRAFFIC_KERNELS = {
+    "gemm_conv": r"gemm_\w+_kernel<unsigned short, 1[,>]",
+    "gemm_logits": r"gemm_\w+_kernel<unsigned short, 2[,>]",
+    "attn_self_step": r"attn_rows_bf16_kernel",
+    "add_layernorm": r"addln_kernel",
+}
+
+
+def committed_traffic(cls, config, precision):
+    """HBM bytes per launch of a kernel class from the committed PMC summary (separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes over one get_reward of THIS workload, gfx950 corrections applied by
+    tools/summarize_profile.py).  PMC counters cannot be collected inside the timed run, so this is the
+    per-launch traffic of the same command measured beforehand; None when no summary matches."""
+    import re
+    if config != "c2" or precision != "bf16" or cls not in TRAFFIC_KERNELS or not os.path.exists(TRAFFIC_FILE):
+        return None
+    ks = json.load(open(TRAFFIC_FILE))["kernels"]
+    hit = [v for k, v in ks.items() if re.search(TRAFFIC_KERNELS[cls], k)]
+    n = sum(v["launches"] for v in hit)
+    return round(sum(v["read_GB"] + v["write_GB"] for v in hit) * 1e9 / n) if n else None
+
+
 def cpu_baseline(cfg, Wg, Wd, x, y, seed_u):
     """Reference-structured CPU path (the oracle's structure-faithful torch-CPU fp32 restatement: full
     re-decode per sampled token, all-position logits, encoder + source tower per call) timed on the
@@ -250,10 +274,13 @@ def main():
         top = max((k for k in rows if "bound" in rows[k]), key=lambda k: rows[k]["ms"])
         r = rows[top]
         result["roofline"] = {"kernel": top, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
-                              "unit": r["unit"], "frac": r["frac"], "traffic": None,
+                              "unit": r["unit"], "frac": r["frac"],
+                              "traffic": committed_traffic(top, args.config, args.precision),
+                              "algorithmic_per_launch": round(r["algorithmic_per_step"] / r["launches"]),
                               "launches": r["launches"], "avg_launch_us": r["avg_us"],
                               "note": "HIP events around every launch of one extra (untimed) step; achieved = "
-                                      "algorithmic work of the class / summed launch time"}
+                                      "algorithmic work of the class / summed launch time; traffic = HBM bytes "
+                                      "per launch from the committed PMC summary profiles/r1_c2_bf16_hbm_traffic.json"}
         result["roofline_all"] = rows
         result["profiled_step_ms"] = round(float(sum(ms)), 2)
 

@@ -7,6 +7,8 @@
 // (teacher-forced prefix of the sentence, or the encoder memory) and the row's private suffix in
 // the step-major rollout cache.  The kernel is HBM/L2-bandwidth bound: per key it moves
 // 2*d*esize bytes for ~5*EPL VALU instructions.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -112,10 +114,157 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
   VecIO<KT, EPL>::store(reinterpret_cast<KT*>(p.out) + (int64_t)row * d + lane * EPL, o);
 }
 
+// ------------------------------------------------------------------------------------------ bf16 fast path
+// Same row-per-wave algorithm for bf16 caches with d = 512 / 1024 (the rollout step's private-suffix pass,
+// 278 GB of K/V per C2 get_reward), tuned for bytes in flight:
+//  - K/V stay packed (16 B per lane and vector) and the NEXT batch of KB keys is requested before the
+//    current one is consumed, so 2*KB*2 vector loads per wave are in flight across the softmax chain;
+//  - head reductions use DPP (quad_perm / row_half_mirror / row_mirror) instead of ds_bpermute;
+//  - scores are kept in log2 units (q pre-scaled by log2 e): every exponential is one v_exp_f32.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float head_sum(float v, int lph) {   // sum over the lph adjacent lanes of a head
+  if (lph > 1) v = dpp_add<0xB1>(v);               // quad_perm [1,0,3,2]
+  if (lph > 2) v = dpp_add<0x4E>(v);               // quad_perm [2,3,0,1]
+  if (lph > 4) v = dpp_add<0x141>(v);              // row_half_mirror
+  if (lph > 8) v = dpp_add<0x140>(v);              // row_mirror
+  if (lph > 16) v += __shfl_xor(v, 16, 64);
+  if (lph > 32) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int EPL, int KB>
+__global__ __launch_bounds__(256) void attn_rows_bf16_kernel(AttnParams p) {
+  constexpr int NV = EPL / 8;                      // 16-byte vectors per lane and key
+  constexpr float LOG2E = 1.44269504088896341f;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int lph = 64 / p.heads;
+  const int d = p.d;
+  const int blk = __builtin_amdgcn_readfirstlane(p.seg1_blk ? p.seg1_blk[row] : (p.rows_per_blk > 0 ? row / p.rows_per_blk : 0));
+  int cnt1 = 0;
+  if (p.k1) cnt1 = p.seg1_cnt ? p.seg1_cnt[row] : (p.causal ? row % p.rows_per_blk + 1 : p.len1);
+  cnt1 = __builtin_amdgcn_readfirstlane(cnt1);
+  const int n_total = cnt1 + p.n_steps2;
+  const bf16_t* k1 = reinterpret_cast<const bf16_t*>(p.k1) + ((int64_t)blk * p.len1) * d + lane * EPL;
+  const bf16_t* v1 = reinterpret_cast<const bf16_t*>(p.v1) + ((int64_t)blk * p.len1) * d + lane * EPL;
+  const bf16_t* k2 = reinterpret_cast<const bf16_t*>(p.k2) + (int64_t)row * d + lane * EPL;
+  const bf16_t* v2 = reinterpret_cast<const bf16_t*>(p.v2) + (int64_t)row * d + lane * EPL;
+  const uint8_t* mk = p.mask1 ? p.mask1 + (int64_t)blk * p.len1 : nullptr;
+
+  float q[EPL];
+  VecIO<float, EPL>::load(p.q + (int64_t)row * d + lane * EPL, q);
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) q[e] *= LOG2E;
+
+  float m = -INFINITY, l = 0.f;                    // m in log2 units
+  float o[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+  if (p.o_init) {
+    const int head = (lane * EPL) / (d / p.heads);
+    m = p.m_init[(int64_t)row * p.heads + head] * LOG2E;
+    l = p.l_init[(int64_t)row * p.heads + head];
+    VecIO<float, EPL>::load(p.o_init + (int64_t)row * d + lane * EPL, o);
+  }
+
+  uint4 kc[KB][NV], vc[KB][NV], kn[KB][NV], vn[KB][NV];
+  unsigned okc = 0, okn = 0;                       // bit u: key u of the batch is valid
+  auto fetch = [&](int jb, uint4 (&kr)[KB][NV], uint4 (&vr)[KB][NV], unsigned& okm) {
+    okm = 0;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const int j = jb + u;                        // wave-uniform
+      if (j < cnt1) {                              // uniform branches: the loads sit inside them on purpose
+        if (!(mk && mk[j])) {                      // (a pointer select here is lowered to a scratch array)
+          okm |= 1u << u;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            kr[u][i] = reinterpret_cast<const uint4*>(k1 + (int64_t)j * d)[i];
+            vr[u][i] = reinterpret_cast<const uint4*>(v1 + (int64_t)j * d)[i];
+          }
+        }
+      } else if (j < n_total) {
+        const int64_t off = p.step_off[j - cnt1] * (int64_t)d;
+        okm |= 1u << u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          kr[u][i] = reinterpret_cast<const uint4*>(k2 + off)[i];
+          vr[u][i] = reinterpret_cast<const uint4*>(v2 + off)[i];
+        }
+      }
+    }
+  };
+  auto unpack = [](const uint4 (&r)[NV], float (&f)[EPL]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f[8 * i + 0] = __uint_as_float(r[i].x << 16); f[8 * i + 1] = __uint_as_float(r[i].x & 0xffff0000u);
+      f[8 * i + 2] = __uint_as_float(r[i].y << 16); f[8 * i + 3] = __uint_as_float(r[i].y & 0xffff0000u);
+      f[8 * i + 4] = __uint_as_float(r[i].z << 16); f[8 * i + 5] = __uint_as_float(r[i].z & 0xffff0000u);
+      f[8 * i + 6] = __uint_as_float(r[i].w << 16); f[8 * i + 7] = __uint_as_float(r[i].w & 0xffff0000u);
+    }
+  };
+  auto consume = [&](const uint4 (&kr)[KB][NV], const uint4 (&vr)[KB][NV], unsigned okm) {
+    float s[KB];
+    float mx = m;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      float part = 0.f;
+      const bool ok = (okm >> u) & 1;
+      if (ok) {
+        float kf[EPL];
+        unpack(kr[u], kf);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) part = fmaf(q[e], kf[e], part);
+      }
+      part = head_sum(part, lph);
+      s[u] = ok ? part : -INFINITY;
+      mx = fmaxf(mx, s[u]);
+    }
+    if (mx == -INFINITY) return;
+    const float alpha = __builtin_amdgcn_exp2f(m - mx);
+    l *= alpha;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      if ((okm >> u) & 1) {
+        const float w = __builtin_amdgcn_exp2f(s[u] - mx);
+        l += w;
+        float vf[EPL];
+        unpack(vr[u], vf);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = fmaf(w, vf[e], o[e]);
+      }
+    }
+    m = mx;
+  };
+
+  fetch(0, kc, vc, okc);
+  for (int jb = 0; jb < n_total; jb += 2 * KB) {
+    fetch(jb + KB, kn, vn, okn);
+    consume(kc, vc, okc);
+    fetch(jb + 2 * KB, kc, vc, okc);
+    consume(kn, vn, okn);
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] *= inv;
+  VecIO<bf16_t, EPL>::store(reinterpret_cast<bf16_t*>(p.out) + (int64_t)row * d + lane * EPL, o);
+}
+
 template <typename KT>
 static int launch_attn_t(const AttnParams& p, hipStream_t st) {
   const int epl = p.d / 64;
   dim3 grid((p.M + 3) / 4), block(256);
+  if constexpr (sizeof(KT) == 2) {
+    static const bool fast = [] { const char* e = getenv("NMTGAN_ATTN_FAST"); return !e || atoi(e) != 0; }();
+    if (fast && epl == 8) { hipLaunchKernelGGL((attn_rows_bf16_kernel<8, 4>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
+    if (fast && epl == 16) { hipLaunchKernelGGL((attn_rows_bf16_kernel<16, 2>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
+  }
   switch (epl) {
     case 1: hipLaunchKernelGGL((attn_rows_kernel<KT, 1, 4>), grid, block, 0, st, p); break;
     case 2: hipLaunchKernelGGL((attn_rows_kernel<KT, 2, 4>), grid, block, 0, st, p); break;

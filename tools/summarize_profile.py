@@ -1,0 +1,67 @@
+"""Condense rocprofv3 outputs into the small files committed under profiles/.
+
+usage: summarize_profile.py TAG STATS_DIR [FETCH_DIR WRITE_DIR] [--steps N]
+  STATS_DIR : output dir of `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`
+  FETCH_DIR / WRITE_DIR : output dirs of separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over ONE
+  get_reward (bench.py --steps 1 --warmup 0 --no-roofline).
+Writes profiles/TAG_kernel_stats.csv (per-kernel calls / total / average) and, with the PMC dirs,
+profiles/TAG_hbm_traffic.json: per kernel HBM bytes read / written per launch.  FETCH_SIZE and WRITE_SIZE
+are reported in KiB; on gfx950 FETCH_SIZE counts 64-byte requests as 32 bytes, hence the x2
+(MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not hits:
+        raise SystemExit("no *%s under %s" % (suffix, d))
+    return hits[0]
+
+
+def short(name):
+    name = name.replace("void ", "").replace("nmtgan::", "")
+    return name.split("(")[0]
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    tag, stats_dir = args[0], args[1]
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    rows = list(csv.DictReader(open(find(stats_dir, "kernel_stats.csv"))))
+    with open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as f:
+        f.write("kernel,calls,total_ms,avg_us,percent\n")
+        for r in rows:
+            f.write("%s,%s,%.3f,%.2f,%s\n" % (short(r["Name"]).replace(",", ";"), r["Calls"],
+                                             float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
+                                             r["Percentage"]))
+    print("wrote", tag + "_kernel_stats.csv", "(%d kernels)" % len(rows))
+    if len(args) >= 4:
+        agg = collections.defaultdict(lambda: {"launches": 0, "read_bytes": 0.0, "write_bytes": 0.0})
+        for key, d, mult in (("read_bytes", args[2], 2.0), ("write_bytes", args[3], 1.0)):
+            seen = collections.Counter()
+            for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+                k = short(r["Kernel_Name"])
+                agg[k][key] += float(r["Counter_Value"]) * 1024.0 * mult
+                seen[k] += 1
+            for k, n in seen.items():
+                agg[k]["launches"] = n
+        out = {}
+        for k, v in sorted(agg.items(), key=lambda kv: -(kv[1]["read_bytes"] + kv[1]["write_bytes"])):
+            n = max(v["launches"], 1)
+            out[k] = {"launches": v["launches"], "read_GB": round(v["read_bytes"] / 1e9, 3),
+                      "write_GB": round(v["write_bytes"] / 1e9, 3),
+                      "bytes_per_launch": round((v["read_bytes"] + v["write_bytes"]) / n)}
+        json.dump({"note": "one get_reward (C2, bf16); FETCH_SIZE x2 (gfx950) and WRITE_SIZE, KiB units",
+                   "total_GB": round(sum(v["read_GB"] + v["write_GB"] for v in out.values()), 1), "kernels": out},
+                  open(os.path.join(out_dir, tag + "_hbm_traffic.json"), "w"), indent=1)
+        print("wrote", tag + "_hbm_traffic.json")
+
+
+if __name__ == "__main__":
+    main()
