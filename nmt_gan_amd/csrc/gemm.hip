@@ -43,6 +43,11 @@ struct GemmParams {
   int a_group; int64_t a_group_stride_b;
   int64_t ldw_b;            // bytes per Wt row (= K*esize)
   int kbytes;               // K * esize
+  // k-tile visiting order (same for both operands): k_inner tiles k_step bytes apart, then k_jump to the next
+  // run.  Plain GEMM: k_inner = 1, k_jump = 128.  Conv windows (K = w taps x E channels): the taps of one
+  // 128-byte channel block are visited back to back, so consecutive k-tiles of A are the same rows of the
+  // sentence image shifted by one token and hit in L2 instead of being re-fetched w times through the fabric.
+  int k_inner; int64_t k_step, k_jump;
   int ntm, ntn, group_m;
   // linear epilogue
   const float* bias; int relu; int n_seg; int seg_width; int wide_ok;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64)) void gemm_glds_kernel(G
   auto stage = [&](int buf, int kt) {
 #pragma unroll
     for (int j = 0; j < NINST; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + (int64_t)kt * BKB),
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + (kt % p.k_inner) * p.k_step + (int64_t)(kt / p.k_inner) * BKB),
                                        (lds_ptr_t)(smem + buf * STAGE + (wave + j * NW) * 1024), 16, 0, 0);
   };
 
@@ -359,9 +364,11 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
 
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
   const char* src[PNINST];
+  int kin = 0;                                   // position inside the run of k_inner k-tiles
   auto set_src = [&](int L) {
     int tm, tn;
     tile_of(L, tm, tn);
+    kin = 0;
 #pragma unroll
     for (int j = 0; j < PNINST; ++j) {
       const int rho = 8 * (wave + j * PNW) + (lane >> 3);
@@ -372,10 +379,14 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
   };
   int is_buf = 0;                                // LDS stage the next issue() fills
   auto issue = [&]() {                           // one k-tile of the tile `src` points at; advances src
+    kin += 1;
+    const bool run_end = kin == p.k_inner;
+    const int64_t adv = run_end ? p.k_jump : p.k_step;
+    if (run_end) kin = 0;
 #pragma unroll
     for (int j = 0; j < PNINST; ++j) {
       glds16(src[j], lds_base + is_buf * PSTAGE + (wave + j * PNW) * 1024);
-      src[j] += BKB;
+      src[j] += adv;
     }
     is_buf = is_buf == 2 ? 0 : is_buf + 1;
   };
@@ -534,8 +545,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmParams p) {
   using U2 = std::integral_constant<int, 2>;
   using U3 = std::integral_constant<int, 3>;
   const char* src[4][2];
+  int kin[4];                                    // position of unit u inside its run of k_inner k-tiles
   auto point = [&](auto U, int ord) {            // unit U's sources at k-tile 0 of the block's tile `ord`
     constexpr int u = decltype(U)::value;
+    kin[u] = 0;
     int tm, tn;
     tile_of((int)blockIdx.x + ord * G, tm, tn);
 #pragma unroll
@@ -556,8 +569,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmParams p) {
     const unsigned dst = lds_base + parity * QSTAGE + u * QUNIT + wave * 1024;
     glds16_m0(src[u][0], dst);
     glds16_m0(src[u][1], dst + 8 * 1024);
-    src[u][0] += BKB;
-    src[u][1] += BKB;
+    kin[u] += 1;
+    const bool run_end = kin[u] == p.k_inner;
+    const int64_t adv = run_end ? p.k_jump : p.k_step;
+    if (run_end) kin[u] = 0;
+    src[u][0] += adv;
+    src[u][1] += adv;
   };
 
   f32x16 acc[4][2];
@@ -926,6 +943,7 @@ int launch_gemm_stats(int op_dtype, const void* W, int V, const void* X, int row
   p.A = (const char*)W; p.W = (const char*)X;
   p.M = V; p.N = rows; p.K = K;
   p.lda_b = (int64_t)K * es; p.ldw_b = (int64_t)K * es; p.kbytes = K * es;
+  p.k_inner = 1; p.k_step = BKB; p.k_jump = BKB;
   p.stats = stats;
   static const bool stats_p8 = [] { const char* e = getenv("NMTGAN_STATS_P8"); return !e || atoi(e) != 0; }();
   if (stats_p8 && prefer_p8(V, rows, p.kbytes / BKB))
@@ -957,6 +975,13 @@ int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st) {
   p.a_group_stride_b = a->a_group_stride * es;
   p.ldw_b = (int64_t)a->K * es;
   p.kbytes = a->K * es;
+  p.k_inner = 1; p.k_step = BKB; p.k_jump = BKB;
+  static const bool tap_order = [] { const char* e = getenv("NMTGAN_CONV_TAPORDER"); return !e || atoi(e) != 0; }();
+  if (tap_order && a->a_group > 0 && a->lda > 0 && a->lda < a->K && a->K % a->lda == 0 && (a->lda * es) % BKB == 0) {
+    p.k_inner = (int)(a->K / a->lda);            // taps
+    p.k_step = a->lda * es;                      // next tap, same channel block
+    p.k_jump = BKB - (int64_t)(p.k_inner - 1) * p.k_step;   // back to tap 0, next channel block
+  }
   if (a->epilogue == NMTGAN_EPI_LINEAR) {
     NMTGAN_REQUIRE(a->n_seg >= 1 && a->n_seg <= 3, "gemm: n_seg must be 1..3");
     NMTGAN_REQUIRE(a->n_seg == 1 || (a->seg_width > 0 && a->seg_width * a->n_seg >= a->N),
