@@ -1,0 +1,157 @@
+"""Full-size (BASELINE.json configs[1] = C2: d512 N6 h8, B64 R16 T50 V32000, bf16) checks of the
+rollout-reward path through properties that do not need the oracle to replay 1.25 M sampled tokens
+(SURVEY section 8c/8d): determinism, prefix preservation, shard invariance (uniforms are addressed by
+global sentence id), range and masking of the rewards, the reward tail recomputed on the host in the
+reference's order (model.py:334-345), and oracle spot checks of the sampler (first sampled token of a
+rollout from the GPU's own prefix logits, full V) and of the discriminator (a few rollouts, fp64 CPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nmtgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+D, BLOCKS, HEADS, V, E, T, R, B = 512, 6, 8, 32000, 512, 50, 16, 64
+
+
+@pytest.fixture(scope="module")
+def c2(cuda):
+    import nmt_gan_amd as N
+    from nmt_gan_amd import synthetic
+    from nmt_gan_amd.utils import AttrDict as Cfg
+    Wg = synthetic.generator_weights(D, BLOCKS, V, V, seed=0)
+    Wd = synthetic.discriminator_weights(T, E, V, V, seed=1)
+    widths, nfs = synthetic.disc_filters(T)
+    mcfg = Cfg(hidden_units=D, num_blocks=BLOCKS, num_heads=HEADS, src_vocab_size=V, dst_vocab_size=V,
+               scale_embedding=True, residual_dropout_rate=0.0, train=Cfg(shared_embedding=False))
+    model = N.Model(mcfg, precision="bf16")
+    model.build_train_model()
+    model.build_generate(T)
+    model.build_rollout_generate(T)
+    model.init_and_restore(weights=Wg)
+    disc = N.DisCNN(None, T, 2, V, B, E, widths, nfs, vocab_size_s=V, precision="bf16")
+    disc.load_weights(Wd)
+    x, y = synthetic.synthetic_batch(B, T, V, V, seed=1234)
+    y[3, 20] = O.EOS_ID                                   # ragged: one early </S>, one very short sample
+    y[7, 2] = O.EOS_ID
+    y, mask = N.deal_generated_samples(y)
+    xp = N.extend_sentence_to_maxlen(x, T)
+    u = model.make_uniforms(R, T, B, seed=2024)
+    r = model.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u, return_details=True)
+    det = model.last_details
+    return dict(model=model, disc=disc, Wd=Wd, x=x, y=y, mask=mask, xp=xp, u=u, r=r, det=det, widths=widths, nfs=nfs)
+
+
+def test_fullsize_shapes_range_and_masking(c2):
+    r, mask = c2["r"], c2["mask"]
+    assert r.shape == (B, T) and r.dtype == np.float32 and np.isfinite(r).all()
+    assert np.all(r[mask == 0] == 0)
+    live = r[mask != 0]
+    assert live.min() >= -0.6 - 1e-6 and live.max() <= 0.4 + 1e-6      # (P - 0.6) with P in [0, 1]
+    assert live.std() > 1e-4                                            # the head is not saturated
+
+
+def test_fullsize_rollouts_keep_prefix_and_mask(c2):
+    det, y = c2["det"], c2["y"]
+    plan = det["plan"]
+    rolls = det["rollouts"][:plan.n_rows]
+    assert plan.n_rows == R * int((plan.lens - 1).clip(min=0).sum())
+    cols = np.arange(T)[None, :]
+    keep = cols < plan.row_g[:, None]
+    assert np.array_equal(rolls[keep], y[plan.row_b][keep])             # the given prefix is untouched
+    tail = cols >= plan.lens[plan.row_b][:, None]
+    assert np.all(rolls[tail] == 0)                                     # masked with the SAMPLE's mask (model.py:307)
+    sampled = ~keep & ~tail
+    assert rolls[sampled].min() >= 0 and rolls[sampled].max() < V
+    # sampling is not degenerate: the 16 rolls of a prefix do not all coincide
+    first = rolls[np.arange(plan.n_rows), plan.row_g].reshape(-1, R)
+    assert (np.ptp(first, axis=1) > 0).mean() > 0.99
+
+
+def test_fullsize_deterministic(c2):
+    m = c2["model"]
+    r2 = m.get_reward(c2["x"], c2["xp"], c2["y"], c2["mask"], R, c2["disc"], max_len=T, bias_num=0.6,
+                      uniforms=c2["u"], return_details=True)
+    assert np.array_equal(m.last_details["rollouts"], c2["det"]["rollouts"])
+    assert np.array_equal(r2, c2["r"])
+
+
+def test_fullsize_shard_invariance(c2):
+    """Sentences 16..39 computed as their own shard (uniforms addressed by global sentence id) give the
+    rows of the unsharded call: identical tokens, rewards equal up to the kernel-choice dependent
+    accumulation order of the bf16 GEMMs."""
+    m = c2["model"]
+    b0, b1 = 16, 40
+    u_dev = torch.as_tensor(c2["u"]).to(device=m.device, dtype=torch.float32).contiguous()
+    local = m._reward_local(c2["x"][b0:b1], c2["xp"][b0:b1], c2["y"][b0:b1], c2["mask"][b0:b1], R, c2["disc"], T, 0.6,
+                            u_dev, b_offset=b0, B_global=B, return_details=True)
+    torch.cuda.synchronize()
+    r = local.cpu().numpy()
+    plan_full = c2["det"]["plan"]
+    sel = (plan_full.row_b >= b0) & (plan_full.row_b < b1)
+    full_rolls = c2["det"]["rollouts"][:plan_full.n_rows][sel]
+    plan = m.last_details["plan"]
+    rolls = m.last_details["rollouts"][:plan.n_rows]
+    # same (b, r, g) order inside both plans for the selected sentences
+    key_full = np.stack([plan_full.row_b[sel] - b0, plan_full.row_r[sel], plan_full.row_g[sel]], 1)
+    key = np.stack([plan.row_b, plan.row_r, plan.row_g], 1)
+    of, os_ = np.lexsort(key_full.T[::-1]), np.lexsort(key.T[::-1])
+    assert np.array_equal(key_full[of], key[os_])
+    same = (full_rolls[of] == rolls[os_]).all(axis=1).mean()
+    print("shard vs full: identical rollouts %.5f" % same)
+    assert same > 0.999
+    if same == 1.0:
+        assert np.abs(r - c2["r"][b0:b1]).max() < 1e-3
+
+
+def test_fullsize_reward_tail_on_host(c2):
+    """model.py:317-345 restated with numpy on the GPU's own P(real) values."""
+    det, mask = c2["det"], c2["mask"]
+    plan = det["plan"]
+    p_rows, p_base = det["p_rows"][:plan.n_rows].astype(np.float32), det["p_base"].astype(np.float32)
+    q = np.zeros((B, T), np.float32)
+    for r_ in range(R):                                                 # rolls summed in r order
+        add = np.zeros((B, T), np.float32)
+        for b in range(B):
+            for g in range(1, T):
+                f = plan.grp_first[b, g - 1]
+                add[b, g - 1] = p_rows[f + r_] if f >= 0 else p_base[b]
+            add[b, T - 1] = p_base[b]
+        q += add
+    want = ((q - np.float32(0.6 * R)) * mask) / np.float32(R)
+    assert np.abs(want - c2["r"]).max() < 1e-6
+
+
+def test_fullsize_first_token_matches_cdf_oracle(c2):
+    """The first sampled token of rollout (b, r, g) is the CDF inversion of the GPU's own prefix logits
+    row (b, g) with u[r, g-1, b, g]: full-vocabulary check of sampler + indexing on 400 rollouts."""
+    det, u = c2["det"], c2["u"]
+    plan = det["plan"]
+    rolls = det["rollouts"]
+    un = u.cpu().numpy() if torch.is_tensor(u) else np.asarray(u)
+    rng = np.random.default_rng(5)
+    bad = 0
+    for i in rng.choice(plan.n_rows, 400, replace=False):
+        b, r_, g = int(plan.row_b[i]), int(plan.row_r[i]), int(plan.row_g[i])
+        want = O.multinomial_cdf(det["prefix_logits"][b, g], un[r_, g - 1, b, g])
+        bad += int(want != rolls[i, g])
+    assert bad <= 1, bad                                                # a 1e-6 near-tie at most
+
+
+def test_fullsize_discriminator_spot_check(c2):
+    """P(real) of 6 rollouts + 2 samples recomputed by the fp64 oracle discriminator (2 GFLOP each)."""
+    det = c2["det"]
+    plan = det["plan"]
+    rng = np.random.default_rng(6)
+    idx = rng.choice(plan.n_rows, 6, replace=False)
+    dcfg = O.DisConfig(max_len=T, dim_word=E, vocab_size=V, vocab_size_s=V)
+    Wd64 = O.to_torch(c2["Wd"])
+    tgt = det["rollouts"][idx]
+    src = c2["xp"][plan.row_b[idx]]
+    p = O.disc_forward(Wd64, dcfg, tgt.T, src.T).numpy()[:, 1]
+    err = np.abs(p - det["p_rows"][idx]).max()
+    pb = O.disc_forward(Wd64, dcfg, c2["y"][:2].T, c2["xp"][:2].T).numpy()[:, 1]
+    err_b = np.abs(pb - det["p_base"][:2]).max()
+    print("full-size P(real) abs err: rollouts %.3g, samples %.3g" % (err, err_b))
+    assert err < 2e-2 and err_b < 2e-2
