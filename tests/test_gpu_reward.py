@@ -98,10 +98,10 @@ def _gpu_reward(s, precision, bias_num=0.6):
     return r, m.last_details
 
 
-@pytest.mark.parametrize("d,heads", [(64, 4), (128, 4)])
+@pytest.mark.parametrize("d,heads", [(64, 4), (128, 4), (512, 8)])
 def test_get_reward_fp32_matches_oracle(cuda, d, heads):
     """d=64 samples from materialised logits; d=128 (>= 4 k-tiles of fp32) takes the fused
-    logits+sampling path, which never writes the rollout logits."""
+    logits+sampling path, which never writes the rollout logits; d=512 / 8 heads is the production width (head dim 64)."""
     s = _make_setup(d, heads)
     r, det = _gpu_reward(s, "fp32")
     plan = det["plan"]
@@ -141,7 +141,7 @@ def test_get_reward_no_bias_fp32(cuda, setup):
     assert np.abs(r - ref).max() < 1e-5
 
 
-@pytest.mark.parametrize("d,heads", [(64, 4), (128, 4), (256, 4)])
+@pytest.mark.parametrize("d,heads", [(64, 4), (128, 4), (256, 4), (512, 8)])
 def test_get_reward_bf16_token_agreement_and_rewards(cuda, d, heads):
     """bf16 tier: tokens checked per step under forced-identical prefixes - the oracle replays each
     GPU rollout (teacher-forced) and re-samples every position with the same uniform.
