@@ -159,6 +159,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--logits-chunk", type=int, default=None)
     ap.add_argument("--disc-chunk", type=int, default=None)
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1],
+                    help="1: two-stream schedule (discriminator scoring of finished rollouts overlaps the decode steps)")
+    ap.add_argument("--aux-wgs", type=int, default=0)
+    ap.add_argument("--aux-min-rows", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -200,6 +204,8 @@ def main():
         model.logits_chunk_rows = args.logits_chunk
     if args.disc_chunk:
         model.disc_chunk_rows = args.disc_chunk
+    model.overlap = bool(args.overlap)
+    model.aux_gemm_wgs, model.aux_min_rows = args.aux_wgs, args.aux_min_rows
 
     x, y = synthetic.synthetic_batch(Bg, T, V, V, seed=1234)         # no </S>: every row full length T
     y, mask = N.deal_generated_samples(y)

@@ -128,7 +128,7 @@ int nmtgan_add_layernorm(const nmtgan_addln_args* a, void* stream);
  * Segment 2: keys s in [0, n_steps2) at k2 + (step_off[s] + r)*d  (step-major private cache).
  */
 typedef struct {
-  const float* q;            /* [M][d] fp32 */
+  const void* q;             /* [M][d] fp32 (or kv_dtype, see q_op_dtype) */
   int M, d, heads;
   int kv_dtype;              /* dtype of k1,v1,k2,v2 and out */
   const void* k1; const void* v1; int len1;
@@ -139,6 +139,7 @@ typedef struct {
   /* optional running softmax state to continue from (written by nmtgan_attn_group in partial mode):
    * un-normalised o_init[M][d], m_init[M][heads], l_init[M][heads]; all three or none */
   const float* o_init; const float* m_init; const float* l_init;
+  int q_op_dtype;            /* != 0: q is [M][d] in kv_dtype (as written by a GEMM output segment) instead of fp32 */
 } nmtgan_attn_args;
 int nmtgan_attn_rows(const nmtgan_attn_args* a, void* stream);
 
@@ -153,11 +154,12 @@ int nmtgan_attn_rows(const nmtgan_attn_args* a, void* stream);
  * fp32 [M][d], m_part/l_part [M][heads]) that nmtgan_attn_rows continues over private keys.
  */
 typedef struct {
-  const float* q; int M, d, heads, rows_per_group;
+  const void* q; int M, d, heads, rows_per_group;   /* q fp32, or bf16 when q_bf16 != 0 */
   const void* k; const void* vt; int len, len_padded;
   const int32_t* row_blk; const int32_t* row_cnt; const uint8_t* mask;
   void* out;
   float* o_part; float* m_part; float* l_part;
+  int q_bf16;
 } nmtgan_attn_group_args;
 int nmtgan_attn_group(const nmtgan_attn_group_args* a, void* stream);
 /* v[nblk*len][d] bf16 -> vt[nblk][d][len_padded] bf16, zero padded */
@@ -298,6 +300,16 @@ typedef struct {
   const int32_t* row_g_host;        /* HOST copy of row_g, may be NULL.  When given, the discriminator skips
                                        the conv windows that end inside a rollout's given prefix (same value
                                        as in y_sample) and takes their max from one pass over y_sample */
+  /* Two-stream schedule (optional).  A rollout (b, r, g) is complete T-g steps into the lock-step loop,
+   * so the discriminator can score finished rollouts on `aux_stream` while the remaining, ever smaller
+   * decode steps run on `stream`: the conv GEMMs are MFMA-bound, the late decode steps latency/HBM-bound.
+   * The library forks/joins the two streams with events (thread-local pool, created once per device);
+   * results are identical to the single-stream schedule.  NULL or == stream: single stream. */
+  void* aux_stream;
+  int aux_gemm_wgs;                 /* workgroup cap of the persistent GEMMs on aux_stream while decode steps are
+                                       still being issued (leaves CUs to the decoder); 0 = default (160) */
+  int aux_min_rows;                 /* finished rollouts are handed to aux_stream in batches of at least this
+                                       many rows; 0 = default (4096) */
 } nmtgan_reward_plan;
 size_t nmtgan_rollout_reward_workspace_bytes(const nmtgan_generator* g, const nmtgan_discriminator* d,
                                              const nmtgan_reward_plan* plan);

@@ -43,14 +43,14 @@ class AttnArgs(C.Structure):
                 ("k1", vp), ("v1", vp), ("len1", i32),
                 ("seg1_blk", vp), ("seg1_cnt", vp), ("rows_per_blk", i32), ("causal", i32), ("mask1", vp),
                 ("k2", vp), ("v2", vp), ("step_off", vp), ("n_steps2", i32), ("out", vp),
-                ("o_init", vp), ("m_init", vp), ("l_init", vp)]
+                ("o_init", vp), ("m_init", vp), ("l_init", vp), ("q_op_dtype", i32)]
 
 
 class AttnGroupArgs(C.Structure):
     _fields_ = [("q", vp), ("M", i32), ("d", i32), ("heads", i32), ("rows_per_group", i32),
                 ("k", vp), ("vt", vp), ("len", i32), ("len_padded", i32),
                 ("row_blk", vp), ("row_cnt", vp), ("mask", vp), ("out", vp),
-                ("o_part", vp), ("m_part", vp), ("l_part", vp)]
+                ("o_part", vp), ("m_part", vp), ("l_part", vp), ("q_bf16", i32)]
 
 
 class SampleArgs(C.Structure):
@@ -101,7 +101,7 @@ class RewardPlan(C.Structure):
                 ("grp_first", vp), ("uniforms", vp), ("use_bias", i32), ("bias_num", f64),
                 ("logits_chunk_rows", i32), ("disc_chunk_rows", i32),
                 ("rewards", vp), ("rollouts", vp), ("p_rows", vp), ("p_base", vp), ("prefix_logits", vp),
-                ("row_g_host", vp)]
+                ("row_g_host", vp), ("aux_stream", vp), ("aux_gemm_wgs", i32), ("aux_min_rows", i32)]
 
 
 EXPORTS = {

@@ -15,7 +15,7 @@
 namespace nmtgan {
 
 struct AttnParams {
-  const float* q; int M, d, heads;
+  const void* q; int M, d, heads;
   const void* k1; const void* v1; int len1;
   const int32_t* seg1_blk; const int32_t* seg1_cnt; int rows_per_blk; int causal;
   const uint8_t* mask1;
@@ -24,7 +24,7 @@ struct AttnParams {
   const float* o_init; const float* m_init; const float* l_init;
 };
 
-template <typename KT, int EPL, int KB>
+template <typename KT, int EPL, int KB, typename QT>
 __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
   const uint8_t* mk = p.mask1 ? p.mask1 + (int64_t)blk * p.len1 : nullptr;
 
   float q[EPL];
-  VecIO<float, EPL>::load(p.q + (int64_t)row * d + lane * EPL, q);
+  VecIO<QT, EPL>::load(reinterpret_cast<const QT*>(p.q) + (int64_t)row * d + lane * EPL, q);
 
   float m = -INFINITY, l = 0.f;
   float o[EPL];
@@ -135,7 +135,7 @@ __device__ __forceinline__ float head_sum(float v, int lph) {   // sum over the 
   return v;
 }
 
-template <int EPL, int KB>
+template <int EPL, int KB, typename QT>
 __global__ __launch_bounds__(256) void attn_rows_bf16_kernel(AttnParams p) {
   constexpr int NV = EPL / 8;                      // 16-byte vectors per lane and key
   constexpr float LOG2E = 1.44269504088896341f;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_rows_bf16_kernel(AttnParams p) {
   const uint8_t* mk = p.mask1 ? p.mask1 + (int64_t)blk * p.len1 : nullptr;
 
   float q[EPL];
-  VecIO<float, EPL>::load(p.q + (int64_t)row * d + lane * EPL, q);
+  VecIO<QT, EPL>::load(reinterpret_cast<const QT*>(p.q) + (int64_t)row * d + lane * EPL, q);
 #pragma unroll
   for (int e = 0; e < EPL; ++e) q[e] *= LOG2E;
 
@@ -256,21 +256,21 @@ __global__ __launch_bounds__(256) void attn_rows_bf16_kernel(AttnParams p) {
   VecIO<bf16_t, EPL>::store(reinterpret_cast<bf16_t*>(p.out) + (int64_t)row * d + lane * EPL, o);
 }
 
-template <typename KT>
+template <typename KT, typename QT>
 static int launch_attn_t(const AttnParams& p, hipStream_t st) {
   const int epl = p.d / 64;
   dim3 grid((p.M + 3) / 4), block(256);
   if constexpr (sizeof(KT) == 2) {
     static const bool fast = [] { const char* e = getenv("NMTGAN_ATTN_FAST"); return !e || atoi(e) != 0; }();
-    if (fast && epl == 8) { hipLaunchKernelGGL((attn_rows_bf16_kernel<8, 4>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
-    if (fast && epl == 16) { hipLaunchKernelGGL((attn_rows_bf16_kernel<16, 2>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
+    if (fast && epl == 8) { hipLaunchKernelGGL((attn_rows_bf16_kernel<8, 4, QT>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
+    if (fast && epl == 16) { hipLaunchKernelGGL((attn_rows_bf16_kernel<16, 2, QT>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
   }
   switch (epl) {
-    case 1: hipLaunchKernelGGL((attn_rows_kernel<KT, 1, 4>), grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL((attn_rows_kernel<KT, 2, 4>), grid, block, 0, st, p); break;
-    case 4: hipLaunchKernelGGL((attn_rows_kernel<KT, 4, 4>), grid, block, 0, st, p); break;
-    case 8: hipLaunchKernelGGL((attn_rows_kernel<KT, 8, 4>), grid, block, 0, st, p); break;
-    case 16: hipLaunchKernelGGL((attn_rows_kernel<KT, 16, 2>), grid, block, 0, st, p); break;
+    case 1: hipLaunchKernelGGL((attn_rows_kernel<KT, 1, 4, QT>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((attn_rows_kernel<KT, 2, 4, QT>), grid, block, 0, st, p); break;
+    case 4: hipLaunchKernelGGL((attn_rows_kernel<KT, 4, 4, QT>), grid, block, 0, st, p); break;
+    case 8: hipLaunchKernelGGL((attn_rows_kernel<KT, 8, 4, QT>), grid, block, 0, st, p); break;
+    case 16: hipLaunchKernelGGL((attn_rows_kernel<KT, 16, 2, QT>), grid, block, 0, st, p); break;
     default: NMTGAN_FAIL(-2, "attn: d/64 must be 1,2,4,8 or 16 (d=%d)", p.d);
   }
   NMTGAN_CHECK_LAUNCH("attn_rows");
@@ -295,8 +295,8 @@ int launch_attn_rows(const nmtgan_attn_args* a, hipStream_t st) {
                  "attn: o_init/m_init/l_init must be given together");
   AttnParams p{a->q, a->M, a->d, a->heads, a->k1, a->v1, a->len1, a->seg1_blk, a->seg1_cnt, a->rows_per_blk,
                a->causal, a->mask1, a->k2, a->v2, a->step_off, a->n_steps2, a->out, a->o_init, a->m_init, a->l_init};
-  if (a->kv_dtype == NMTGAN_BF16) return launch_attn_t<bf16_t>(p, st);
-  if (a->kv_dtype == NMTGAN_F32) return launch_attn_t<float>(p, st);
+  if (a->kv_dtype == NMTGAN_BF16) return a->q_op_dtype ? launch_attn_t<bf16_t, bf16_t>(p, st) : launch_attn_t<bf16_t, float>(p, st);
+  if (a->kv_dtype == NMTGAN_F32) return launch_attn_t<float, float>(p, st);
   NMTGAN_FAIL(-2, "attn: bad kv_dtype %d", a->kv_dtype);
 }
 

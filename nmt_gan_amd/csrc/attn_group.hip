@@ -23,7 +23,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 struct GroupAttnParams {
-  const float* q;              // [M][d] fp32, already scaled
+  const void* q;               // [M][d] fp32 or bf16 (q_bf16), already scaled
   int M, d, heads, R;          // R rows per group (<= 32)
   const bf16_t* k;             // [nblk][L][d]
   const bf16_t* vt;            // [nblk][d][Lp]
@@ -42,12 +42,17 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
   return r;
 }
 
-template <int DK>
+// One wave per (group, head); a workgroup = 4 heads of one group (grid.y = heads / 4).  The kernel is
+// latency-bound (two 32-key tiles per head at T = Ls = 50, ~30 MFMAs), so every global load of a 64-key
+// pair - q, both K tiles, both V^T tiles, the padding mask - is issued before the first MFMA.
+template <int DK, bool QB>
 __global__ __launch_bounds__(256) void attn_group_kernel(GroupAttnParams p) {
   constexpr int KS = DK / 16;      // k-steps of the QK^T product
   constexpr int DT = DK / 32;      // 32-row tiles of O^T
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, h2 = lane >> 5;
+  const int head = blockIdx.y * 4 + wave;
+  if (head >= p.heads) return;
   const int row0 = blockIdx.x * p.R;
   const int row = row0 + n;
   const bool row_ok = n < p.R && row < p.M;
@@ -56,99 +61,129 @@ __global__ __launch_bounds__(256) void attn_group_kernel(GroupAttnParams p) {
   const int d = p.d;
   const uint8_t* mk = p.mask ? p.mask + (int64_t)blk * p.L : nullptr;
 
-  for (int head = wave; head < p.heads; head += 4) {
-    bf16x8 qf[KS];
+  bf16x8 qf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
+  for (int s = 0; s < KS; ++s) {
+    if constexpr (QB) {
+      uint4 t = make_uint4(0, 0, 0, 0);
+      if (row_ok) t = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.q) + (int64_t)row * d + head * DK + 16 * s + 8 * h2);
+      qf[s] = __builtin_bit_cast(bf16x8, t);
+    } else {
       float t[8];
-      if (row_ok) VecIO<float, 8>::load(p.q + (int64_t)row * d + head * DK + 16 * s + 8 * h2, t);
+      if (row_ok) VecIO<float, 8>::load(reinterpret_cast<const float*>(p.q) + (int64_t)row * d + head * DK + 16 * s + 8 * h2, t);
       else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) t[i] = 0.f;
       }
       qf[s] = pack8(t);
     }
-    f32x16 o[DT];
+  }
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const bf16_t* Kb = p.k + (int64_t)blk * p.L * d + head * DK + 8 * h2;
+  const bf16_t* Vb = p.vt + ((int64_t)blk * d + head * DK + n) * p.Lp + 4 * h2;
+
+  auto load_k = [&](int k0, uint4 (&kr)[KS]) {
+    const int keyc = min(k0 + n, p.L - 1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kr[s] = *reinterpret_cast<const uint4*>(Kb + (int64_t)keyc * d + 16 * s);
+  };
+  auto load_v = [&](int k0, uint4 (&vr)[DT][2]) {
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
-    float m = -INFINITY, l = 0.f;
-    const bf16_t* Kb = p.k + (int64_t)blk * p.L * d + head * DK + 8 * h2;
-    const bf16_t* Vb = p.vt + ((int64_t)blk * d + head * DK + n) * p.Lp + 4 * h2;
-
-    for (int k0 = 0; k0 < cnt; k0 += 32) {
-      f32x16 sacc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-      const int keyc = min(k0 + n, p.L - 1);
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const uint4 kv = *reinterpret_cast<const uint4*>(Kb + (int64_t)keyc * d + 16 * s);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kv), qf[s], sacc, 0, 0, 0);
+      for (int s = 0; s < 2; ++s) {
+        // element j of half h2 must be key 16s + 8(j>>2) + 4*h2 + (j&3) (operand k-order of the acc tile)
+        const bf16_t* vp = Vb + (int64_t)(32 * t) * p.Lp + k0 + 16 * s;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vp + 8);
+        vr[t][s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
-      float sv[16];
-      float mx = -INFINITY;
+  };
+  // one 32-key tile: S^T = K.Q^T, online softmax along the keys, O^T += V^T.P^T; bad = padding bits of the tile
+  auto tile = [&](int k0, const uint4 (&kr)[KS], const uint4 (&vr)[DT][2], unsigned bad) {
+    f32x16 sacc;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int kk = k0 + (e & 3) + 8 * (e >> 2) + 4 * h2;
-        const bool ok = kk < cnt && !(mk && mk[min(kk, p.L - 1)]);
-        sv[e] = ok ? sacc[e] : -INFINITY;
-        mx = fmaxf(mx, sv[e]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m, mx);
-      if (m_new == -INFINITY) continue;           // every key of the tile masked (same for all lanes)
-      const float alpha = __expf(m - m_new);
-      float pv[16];
-      float ls = 0.f;
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        pv[e] = __expf(sv[e] - m_new);
-        ls += pv[e];
-      }
-      ls += __shfl_xor(ls, 32, 64);
-      l = l * alpha + ls;
-      m = m_new;
-      bf16x8 pf[2] = {pack8(pv), pack8(pv + 8)};
+    for (int s = 0; s < KS; ++s)
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kr[s]), qf[s], sacc, 0, 0, 0);
+    float sv[16];
+    float mx = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          // element j of half h2 must be key 16s + 8(j>>2) + 4*h2 + (j&3) (operand k-order of the acc tile)
-          const bf16_t* vp = Vb + (int64_t)(32 * t) * p.Lp + k0 + 16 * s;
-          const uint2 lo = *reinterpret_cast<const uint2*>(vp);
-          const uint2 hi = *reinterpret_cast<const uint2*>(vp + 8);
-          const uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s], o[t], 0, 0, 0);
-        }
-      }
+    for (int e = 0; e < 16; ++e) {
+      const int kt = (e & 3) + 8 * (e >> 2) + 4 * h2;
+      const bool ok = k0 + kt < cnt && !((bad >> kt) & 1u);
+      sv[e] = ok ? sacc[e] : -INFINITY;
+      mx = fmaxf(mx, sv[e]);
     }
-    if (!row_ok) continue;
-    // O^T tile t: this lane = query row n, register e = dv 32t + (e&3) + 8(e>>2) + 4*h2
-    if (p.out) {
-      const float inv = l > 0.f ? 1.f / l : 0.f;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    if (m_new == -INFINITY) return;             // every key of the tile masked (same for all lanes of a row)
+    const float alpha = __expf(m - m_new);
+    float pv[16];
+    float ls = 0.f;
 #pragma unroll
-      for (int t = 0; t < DT; ++t)
+    for (int e = 0; e < 16; ++e) {
+      pv[e] = __expf(sv[e] - m_new);
+      ls += pv[e];
+    }
+    ls += __shfl_xor(ls, 32, 64);
+    l = l * alpha + ls;
+    m = m_new;
+    bf16x8 pf[2] = {pack8(pv), pack8(pv + 8)};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float v4[4] = {o[t][4 * c] * inv, o[t][4 * c + 1] * inv, o[t][4 * c + 2] * inv, o[t][4 * c + 3] * inv};
-          VecIO<bf16_t, 4>::store(p.out + (int64_t)row * d + head * DK + 32 * t + 8 * c + 4 * h2, v4);
-        }
-    } else {
+    for (int t = 0; t < DT; ++t) {
 #pragma unroll
-      for (int t = 0; t < DT; ++t)
+      for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float v4[4] = {o[t][4 * c], o[t][4 * c + 1], o[t][4 * c + 2], o[t][4 * c + 3]};
-          VecIO<float, 4>::store(p.o_part + (int64_t)row * d + head * DK + 32 * t + 8 * c + 4 * h2, v4);
-        }
-      if (h2 == 0) {
-        p.m_part[(int64_t)row * p.heads + head] = m;
-        p.l_part[(int64_t)row * p.heads + head] = l;
+      for (int s = 0; s < 2; ++s)
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vr[t][s]), pf[s], o[t], 0, 0, 0);
+    }
+  };
+
+  for (int k0 = 0; k0 < cnt; k0 += 64) {
+    const bool two = k0 + 32 < cnt;               // wave-uniform
+    uint4 ka[KS], kb[KS], va[DT][2], vb[DT][2];
+    bool mb = false;
+    if (mk) {
+      const int key = k0 + lane;
+      mb = key < p.L && mk[key] != 0;
+    }
+    load_k(k0, ka);
+    if (two) load_k(k0 + 32, kb);
+    load_v(k0, va);
+    if (two) load_v(k0 + 32, vb);                 // two => k0 + 64 <= Lp (Lp is a multiple of 32, >= L >= cnt)
+    const unsigned long long bad = __ballot(mb);
+    tile(k0, ka, va, (unsigned)bad);
+    if (two) tile(k0 + 32, kb, vb, (unsigned)(bad >> 32));
+  }
+  if (!row_ok) return;
+  // O^T tile t: this lane = query row n, register e = dv 32t + (e&3) + 8(e>>2) + 4*h2
+  if (p.out) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v4[4] = {o[t][4 * c] * inv, o[t][4 * c + 1] * inv, o[t][4 * c + 2] * inv, o[t][4 * c + 3] * inv};
+        VecIO<bf16_t, 4>::store(p.out + (int64_t)row * d + head * DK + 32 * t + 8 * c + 4 * h2, v4);
       }
+  } else {
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v4[4] = {o[t][4 * c], o[t][4 * c + 1], o[t][4 * c + 2], o[t][4 * c + 3]};
+        VecIO<float, 4>::store(p.o_part + (int64_t)row * d + head * DK + 32 * t + 8 * c + 4 * h2, v4);
+      }
+    if (h2 == 0) {
+      p.m_part[(int64_t)row * p.heads + head] = m;
+      p.l_part[(int64_t)row * p.heads + head] = l;
     }
   }
 }
@@ -186,13 +221,19 @@ int launch_attn_group(const nmtgan_attn_group_args* a, hipStream_t st) {
   NMTGAN_REQUIRE(a->out || (a->m_part && a->l_part), "attn_group: partial mode needs m_part and l_part");
   GroupAttnParams p{a->q, a->M, a->d, a->heads, a->rows_per_group, (const bf16_t*)a->k, (const bf16_t*)a->vt, a->len,
                     a->len_padded, a->row_blk, a->row_cnt, a->mask, (bf16_t*)a->out, a->o_part, a->m_part, a->l_part};
-  dim3 grid(a->M / a->rows_per_group), block(256);
+  dim3 grid(a->M / a->rows_per_group, (a->heads + 3) / 4), block(256);
+  const bool qb = a->q_bf16 != 0;
+  NMTGAN_REQUIRE(!qb || ((uintptr_t)a->q % 16 == 0 && a->d % 8 == 0), "attn_group: bf16 q must be 16-byte aligned");
+#define NMTGAN_GROUP(DK)                                                                      \
+  if (qb) hipLaunchKernelGGL((attn_group_kernel<DK, true>), grid, block, 0, st, p);           \
+  else hipLaunchKernelGGL((attn_group_kernel<DK, false>), grid, block, 0, st, p)
   switch (a->d / a->heads) {
-    case 32: hipLaunchKernelGGL(attn_group_kernel<32>, grid, block, 0, st, p); break;
-    case 64: hipLaunchKernelGGL(attn_group_kernel<64>, grid, block, 0, st, p); break;
-    case 128: hipLaunchKernelGGL(attn_group_kernel<128>, grid, block, 0, st, p); break;
+    case 32: NMTGAN_GROUP(32); break;
+    case 64: NMTGAN_GROUP(64); break;
+    case 128: NMTGAN_GROUP(128); break;
     default: NMTGAN_FAIL(-2, "attn_group: head dim %d not in {32, 64, 128}", a->d / a->heads);
   }
+#undef NMTGAN_GROUP
   NMTGAN_CHECK_LAUNCH("attn_group");
   return 0;
 }

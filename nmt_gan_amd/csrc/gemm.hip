@@ -460,6 +460,13 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
 #undef NMTGAN_WAIT
 }
 
+static thread_local int g_wg_cap = 0;
+void set_gemm_wg_cap(int cap) { g_wg_cap = cap > 0 ? (cap + 7) / 8 * 8 : 0; }   // multiple of 8: one share per XCD
+static inline int persistent_grid(int nwg) {
+  const int cus = g_wg_cap > 0 && g_wg_cap < 256 ? g_wg_cap : 256;
+  return nwg < cus ? nwg : cus;
+}
+
 template <typename OpT, int EPI>
 static int launch_pipe(GemmParams p, hipStream_t st) {
   constexpr int smem = 3 * PSTAGE + PNW * 2048;  // 3 stages + per-wave epilogue scratch = 160 KiB
@@ -485,7 +492,7 @@ static int launch_pipe(GemmParams p, hipStream_t st) {
     if (const char* e = getenv("NMTGAN_GEMM_WIDE")) p.wide_ok = p.wide_ok && atoi(e);
   }
   const int nwg = p.ntm * p.ntn;
-  const int grid = nwg < 256 ? nwg : 256;        // one block per CU; 256 % 8 == 0 keeps the XCD remap bijective
+  const int grid = persistent_grid(nwg);         // one block per CU; the tile walk is bijective for any grid
   int smem_use = smem;
   if (const char* e = getenv("NMTGAN_GEMM_SMEM")) smem_use = atoi(e);
   hipLaunchKernelGGL((gemm_pipe_kernel<OpT, EPI>), dim3(grid), dim3(512), smem_use, st, p);
@@ -765,7 +772,7 @@ static int launch_p8(GemmParams p, hipStream_t st) {
     p.wide_ok = ok ? 1 : 0;
   }
   const int nwg = p.ntm * p.ntn;
-  const int grid = nwg < 256 ? nwg : 256;
+  const int grid = persistent_grid(nwg);
   hipLaunchKernelGGL((gemm_p8_kernel<OpT, EPI>), dim3(grid), dim3(512), smem, st, p);
   NMTGAN_CHECK_LAUNCH("gemm_p8");
   return 0;

@@ -9,6 +9,9 @@ int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st);
 int launch_gemm_stats(int op_dtype, const void* W, int V, const void* X, int rows, int K, float2* stats,
                       hipStream_t st);
 bool gemm_stats_supported(int op_dtype, int V, int K);
+// cap on the grid of the persistent GEMM kernels launched by this thread (0 = one workgroup per CU);
+// the two-stream rollout schedule uses it to leave CUs to the concurrently running decode steps
+void set_gemm_wg_cap(int cap);
 int launch_logits_sample(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
                          const int64_t* u_off, int64_t u_add, int32_t* out, void* ws, hipStream_t st);
 size_t logits_sample_workspace(int M, int V);

@@ -85,11 +85,11 @@ static int encode(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_
     const nmtgan_enc_block& b = g->enc[l];
     void* outs[3] = {a.q, kbuf, vbuf};
     int64_t ld[3] = {d, d, d};
-    int f32[3] = {1, 0, 0};
+    int f32[3] = {0, 0, 0};                       // q in op dtype like K/V (the attention kernels take it as such)
     float sc[3] = {qscale, 1.f, 1.f};
     NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st));
     nmtgan_attn_args t{};
-    t.q = a.q; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
+    t.q = a.q; t.q_op_dtype = 1; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
     t.k1 = kbuf; t.v1 = vbuf; t.len1 = Ls; t.rows_per_blk = Ls; t.causal = 0; t.mask1 = x_pad; t.out = a.ao;
     NMTGAN_TRY(launch_attn_rows(&t, st));
     NMTGAN_TRY(dense1(op, a.ao, d, M, d, d, b.o, a.yf, d, 1, 1.f, 0, st));
@@ -141,28 +141,28 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
     {
       void* outs[3] = {a.q, at(c.wrK, l * c.wr_layer_stride + c.wr_off, es), at(c.wrV, l * c.wr_layer_stride + c.wr_off, es)};
       int64_t ld[3] = {d, d, d};
-      int f32[3] = {1, 0, 0};
+      int f32[3] = {0, 0, 0};
       float sc[3] = {qscale, 1.f, 1.f};
       NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st));
     }
     if (c.group_R > 0) {
       // shared prefix keys once per group on MFMA -> running (o, m, l); private suffix per row after
       nmtgan_attn_group_args ga{};
-      ga.q = a.q; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
+      ga.q = a.q; ga.q_bf16 = 1; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
       ga.k = at(c.shK, l * c.sh_layer_stride, es); ga.vt = at(c.shVt, l * c.sht_layer_stride, es);
       ga.len = c.len_sh; ga.len_padded = c.sh_Lp; ga.row_blk = c.seg1_blk; ga.row_cnt = c.seg1_cnt;
       ga.o_part = c.o_part; ga.m_part = c.m_part; ga.l_part = c.l_part;
       prof::Hint ph(prof::ATTN_SELF);
       NMTGAN_TRY(launch_attn_group(&ga, st));
       nmtgan_attn_args t{};
-      t.q = a.q; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
+      t.q = a.q; t.q_op_dtype = 1; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
       t.k2 = at(c.prK, l * c.pr_layer_stride, es); t.v2 = at(c.prV, l * c.pr_layer_stride, es);
       t.step_off = c.step_off; t.n_steps2 = c.n_steps2;
       t.o_init = c.o_part; t.m_init = c.m_part; t.l_init = c.l_part; t.out = a.ao;
       NMTGAN_TRY(launch_attn_rows(&t, st));
     } else {
       nmtgan_attn_args t{};
-      t.q = a.q; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
+      t.q = a.q; t.q_op_dtype = 1; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
       if (c.shK) {
         t.k1 = at(c.shK, l * c.sh_layer_stride, es); t.v1 = at(c.shV, l * c.sh_layer_stride, es);
         t.len1 = c.len_sh; t.seg1_blk = c.seg1_blk; t.seg1_cnt = c.seg1_cnt; t.rows_per_blk = c.rows_per_blk;
@@ -178,17 +178,17 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
     }
     NMTGAN_TRY(dense1(op, a.ao, d, M, d, d, b.o, a.yf, d, 1, 1.f, 0, st));
     NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln0, M, a.xo, nullptr, st));
-    NMTGAN_TRY(dense1(op, a.xo, d, M, d, d, b.cq, a.q, d, 1, qscale, 0, st));
+    NMTGAN_TRY(dense1(op, a.xo, d, M, d, d, b.cq, a.q, d, 0, qscale, 0, st));
     if (c.group_R > 0) {
       nmtgan_attn_group_args ga{};
-      ga.q = a.q; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
+      ga.q = a.q; ga.q_bf16 = 1; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
       ga.k = at(c.crossK, l * c.cross_layer_stride, es); ga.vt = at(c.crossVt, l * c.crosst_layer_stride, es);
       ga.len = c.Ls; ga.len_padded = c.cross_Lp; ga.row_blk = c.cross_blk; ga.mask = c.x_pad; ga.out = a.ao;
       prof::Hint ph(prof::ATTN_CROSS);
       NMTGAN_TRY(launch_attn_group(&ga, st));
     } else {
       nmtgan_attn_args t{};
-      t.q = a.q; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
+      t.q = a.q; t.q_op_dtype = 1; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
       t.k1 = at(c.crossK, l * c.cross_layer_stride, es); t.v1 = at(c.crossV, l * c.cross_layer_stride, es);
       t.len1 = c.Ls; t.seg1_blk = c.cross_blk; t.rows_per_blk = c.cross_rows_per_blk; t.causal = 0;
       t.mask1 = c.x_pad; t.out = a.ao;
@@ -361,6 +361,27 @@ int disc_features(const nmtgan_discriminator* d, int source, const int32_t* ids,
 }
 
 // ------------------------------------------------------------------------------------------ rollout reward
+// Fork/join events of the two-stream schedule: a thread-local pool per device, created on first use (host
+// objects, no device memory), re-recorded call after call (a wait captures the record that precedes it).
+struct SyncEvents {
+  size_t used = 0;
+  int order(hipStream_t first, hipStream_t then) {        // work enqueued on `then` from now on runs after
+    static thread_local std::vector<hipEvent_t> pool[16]; //   everything enqueued on `first` so far
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) NMTGAN_FAIL(-3, "two-stream: bad device");
+    std::vector<hipEvent_t>& ev = pool[dev];
+    if (used == ev.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) NMTGAN_FAIL(-3, "two-stream: event create failed");
+      ev.push_back(e);
+    }
+    hipEvent_t e = ev[used++];
+    if (hipEventRecord(e, first) != hipSuccess || hipStreamWaitEvent(then, e, 0) != hipSuccess)
+      NMTGAN_FAIL(-3, "two-stream: event record/wait failed");
+    return 0;
+  }
+};
+
 struct RewardBufs {
   Act act;
   void *kbuf, *vbuf, *crossK, *crossV, *shK, *shV, *prK, *prV;
@@ -499,6 +520,57 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
                                     at(b.crossVt, (int64_t)l * B * dm * b.Lsp, es), B, Ls, b.Lsp, dm, st));
     }
   }
+  // Two-stream schedule: everything the discriminator does goes to `aux`; it only needs finished rollouts.
+  hipStream_t aux = p->aux_stream ? (hipStream_t)p->aux_stream : st;
+  const bool ovl = aux != st;
+  SyncEvents ev;
+  static const int env_wgs = [] { const char* e = getenv("NMTGAN_AUX_WGS"); return e ? atoi(e) : 0; }();
+  static const int env_min = [] { const char* e = getenv("NMTGAN_AUX_MIN_ROWS"); return e ? atoi(e) : 0; }();
+  const int aux_wgs = env_wgs > 0 ? env_wgs : (p->aux_gemm_wgs > 0 ? p->aux_gemm_wgs : 160);
+  const int aux_min = env_min > 0 ? env_min : (p->aux_min_rows > 0 ? p->aux_min_rows : 4096);
+  struct CapGuard { ~CapGuard() { set_gemm_wg_cap(0); } } cap_guard;
+
+  // discriminator work that does not depend on the rollouts: source tower once per sentence, target tower of
+  // y_sample itself, and the window values of y_sample the rollouts re-use
+  auto disc_static = [&](hipStream_t ds) -> int {
+    for (int r0 = 0; r0 < B; r0 += b.disc_chunk) {
+      const int rows = B - r0 < b.disc_chunk ? B - r0 : b.disc_chunk;
+      NMTGAN_TRY(disc_features_chunk(d, d->src, p->x_pad_to_T + (int64_t)r0 * T, rows, b.feat_s + (int64_t)r0 * d->Fp,
+                                     b.disc, ds));
+    }
+    for (int r0 = 0; r0 < B; r0 += b.disc_chunk) {
+      const int rows = B - r0 < b.disc_chunk ? B - r0 : b.disc_chunk;
+      NMTGAN_TRY(disc_features_chunk(d, d->tgt, p->y + (int64_t)r0 * T, rows, b.feat_t, b.disc, ds));
+      NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s + (int64_t)r0 * d->Fp, nullptr, rows, d->Fp, d->head_w, d->head_b,
+                                  b.p_base + r0, nullptr, ds));
+    }
+    if (b.reuse) {
+      for (int r0 = 0; r0 < B; r0 += b.disc_chunk) {
+        const int rows = B - r0 < b.disc_chunk ? B - r0 : b.disc_chunk;
+        NMTGAN_TRY(disc_window_values(d, d->tgt, p->y + (int64_t)r0 * T, rows, b.win_vals, b.disc, ds));
+        NMTGAN_TRY(launch_prefix_max(b.win_vals, b.win_pm + (int64_t)r0 * T * d->Fp, rows, T, d->Fp, d->n_widths,
+                                     d->widths, d->n_filters, ds));
+      }
+    }
+    return 0;
+  };
+  // target tower + head of the rollout rows [lo, hi)
+  auto disc_rows = [&](int lo, int hi, hipStream_t ds) -> int {
+    for (int r0 = lo; r0 < hi; r0 += b.disc_chunk) {
+      const int rows = hi - r0 < b.disc_chunk ? hi - r0 : b.disc_chunk;
+      PrefixReuse pr{b.win_pm, p->row_b + r0, p->row_g + r0, b.reuse ? p->row_g_host + r0 : nullptr};
+      NMTGAN_TRY(disc_features_chunk(d, d->tgt, b.Y + (int64_t)r0 * T, rows, b.feat_t, b.disc, ds, b.reuse ? &pr : nullptr));
+      NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s, p->row_b + r0, rows, d->Fp, d->head_w, d->head_b, b.p_rows + r0,
+                                  nullptr, ds));
+    }
+    return 0;
+  };
+  if (ovl) {
+    NMTGAN_TRY(ev.order(st, aux));          // the caller's uploads and the previous call's readers come first
+    set_gemm_wg_cap(aux_wgs);
+    NMTGAN_TRY(disc_static(aux));
+    set_gemm_wg_cap(0);
+  }
   // 3. rollouts
   if (p->n_rows > 0) {
     NMTGAN_TRY(launch_init_rollouts(p->y, p->row_b, p->row_g, p->n_rows, T, b.Y, st));
@@ -508,6 +580,21 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
     s.u = p->uniforms; s.u_off = p->row_uoff; s.u_add = 0; s.out = b.tok_cur;
     NMTGAN_TRY(launch_sample_rows(&s, st));
     NMTGAN_TRY(launch_scatter_tokens(b.tok_cur, p->row_g, 0, p->n_rows, T, b.Y, st));
+    // rows [live[s+1], live[s]) are complete once step s has scattered its tokens: hand them to aux
+    int done_hi = p->n_rows;
+    auto hand_over = [&](int step) -> int {
+      if (!ovl) return 0;
+      const int lo = step < p->n_steps ? p->live[step + 1] : 0;
+      if (done_hi - lo < aux_min && step < p->n_steps) return 0;
+      if (done_hi == lo) return 0;
+      NMTGAN_TRY(ev.order(st, aux));
+      set_gemm_wg_cap(step < p->n_steps ? aux_wgs : 0);
+      const int rc = disc_rows(lo, done_hi, aux);
+      set_gemm_wg_cap(0);
+      done_hi = lo;
+      return rc;
+    };
+    NMTGAN_TRY(hand_over(0));
     for (int step = 1; step <= p->n_steps; ++step) {
       const int M = p->live[step];
       nmtgan_embed_args e{};
@@ -539,34 +626,15 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
         NMTGAN_TRY(launch_sample_rows(&q, st));
       }
       NMTGAN_TRY(launch_scatter_tokens(b.tok_cur, p->row_g, step, M, T, b.Y, st));
+      NMTGAN_TRY(hand_over(step));
     }
   }
-  // 4. discriminator: source tower once per sentence, target tower per rollout + once for y_sample
-  for (int r0 = 0; r0 < B; r0 += b.disc_chunk) {
-    const int rows = B - r0 < b.disc_chunk ? B - r0 : b.disc_chunk;
-    NMTGAN_TRY(disc_features_chunk(d, d->src, p->x_pad_to_T + (int64_t)r0 * T, rows, b.feat_s + (int64_t)r0 * d->Fp,
-                                   b.disc, st));
-  }
-  for (int r0 = 0; r0 < B; r0 += b.disc_chunk) {
-    const int rows = B - r0 < b.disc_chunk ? B - r0 : b.disc_chunk;
-    NMTGAN_TRY(disc_features_chunk(d, d->tgt, p->y + (int64_t)r0 * T, rows, b.feat_t, b.disc, st));
-    NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s + (int64_t)r0 * d->Fp, nullptr, rows, d->Fp, d->head_w, d->head_b,
-                                b.p_base + r0, nullptr, st));
-  }
-  if (b.reuse) {
-    for (int r0 = 0; r0 < B; r0 += b.disc_chunk) {
-      const int rows = B - r0 < b.disc_chunk ? B - r0 : b.disc_chunk;
-      NMTGAN_TRY(disc_window_values(d, d->tgt, p->y + (int64_t)r0 * T, rows, b.win_vals, b.disc, st));
-      NMTGAN_TRY(launch_prefix_max(b.win_vals, b.win_pm + (int64_t)r0 * T * d->Fp, rows, T, d->Fp, d->n_widths, d->widths,
-                                   d->n_filters, st));
-    }
-  }
-  for (int r0 = 0; r0 < p->n_rows; r0 += b.disc_chunk) {
-    const int rows = p->n_rows - r0 < b.disc_chunk ? p->n_rows - r0 : b.disc_chunk;
-    PrefixReuse pr{b.win_pm, p->row_b + r0, p->row_g + r0, b.reuse ? p->row_g_host + r0 : nullptr};
-    NMTGAN_TRY(disc_features_chunk(d, d->tgt, b.Y + (int64_t)r0 * T, rows, b.feat_t, b.disc, st, b.reuse ? &pr : nullptr));
-    NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s, p->row_b + r0, rows, d->Fp, d->head_w, d->head_b, b.p_rows + r0,
-                                nullptr, st));
+  // 4. discriminator (single-stream schedule: after the rollouts)
+  if (!ovl) {
+    NMTGAN_TRY(disc_static(st));
+    NMTGAN_TRY(disc_rows(0, p->n_rows, st));
+  } else {
+    NMTGAN_TRY(ev.order(aux, st));
   }
   // 5. per-prefix averaging
   return launch_reward_reduce(b.p_rows, b.p_base, p->grp_first, p->mask, B, T, p->rollnum, p->use_bias, p->bias_num,

@@ -71,6 +71,11 @@ class Model(object):
         self._ws = None
         self.logits_chunk_rows = 4096
         self.disc_chunk_rows = 8192
+        # two-stream schedule of get_reward (discriminator scoring of finished rollouts overlaps the decode steps)
+        self.overlap = True
+        self.aux_gemm_wgs = 0          # 0 = library default
+        self.aux_min_rows = 0
+        self._aux_stream = None
         self.last_details = None
 
     # ------------------------------------------------------------------ graph-building surface
@@ -326,6 +331,11 @@ class Model(object):
         p.logits_chunk_rows = self.logits_chunk_rows
         p.disc_chunk_rows = self.disc_chunk_rows
         p.rewards = ptr(t["rewards"])
+        if self.overlap:
+            if self._aux_stream is None:
+                self._aux_stream = torch.cuda.Stream(device=dev)
+            p.aux_stream = self._aux_stream.cuda_stream
+            p.aux_gemm_wgs, p.aux_min_rows = int(self.aux_gemm_wgs), int(self.aux_min_rows)
         details = None
         if return_details:
             details = {

@@ -172,15 +172,19 @@ def _attn_ref(q, keys, vals, heads):
     return out
 
 
+@pytest.mark.parametrize("q_op", [0, 1])
 @pytest.mark.parametrize("kv", ["bf16", "fp32"])
 @pytest.mark.parametrize("d,heads", [(64, 4), (256, 4), (512, 8), (1024, 16)])
-def test_attn_rows_two_segments(cuda, kv, d, heads):
-    """shared prefix (per-row block + count, with a padding mask) + private step-major suffix."""
+def test_attn_rows_two_segments(cuda, kv, d, heads, q_op):
+    """shared prefix (per-row block + count, with a padding mask) + private step-major suffix;
+    q in fp32 or (q_op) in the K/V dtype as the QKV GEMM writes it."""
     L = _lib()
     g = torch.Generator().manual_seed(d + heads)
     dt = torch.bfloat16 if kv == "bf16" else torch.float32
     nblk, len1, M, nsteps = 3, 9, 10, 5
     q = (torch.randn(M, d, generator=g) * 0.3).to(cuda)
+    if q_op:
+        q = q.to(dt)
     k1 = torch.randn(nblk, len1, d, generator=g).to(dt).to(cuda)
     v1 = torch.randn(nblk, len1, d, generator=g).to(dt).to(cuda)
     blk = torch.randint(0, nblk, (M,), generator=g, dtype=torch.int32).to(cuda)
@@ -196,7 +200,7 @@ def test_attn_rows_two_segments(cuda, kv, d, heads):
     Mlive = live[-1]          # rows alive at the last step attend to all 5 private keys
     out = torch.empty(Mlive, d, device=cuda, dtype=dt)
     a = L.AttnArgs()
-    a.q, a.M, a.d, a.heads = q.data_ptr(), Mlive, d, heads
+    a.q, a.M, a.d, a.heads, a.q_op_dtype = q.data_ptr(), Mlive, d, heads, q_op
     a.kv_dtype = L.NMTGAN_BF16 if kv == "bf16" else L.NMTGAN_F32
     a.k1, a.v1, a.len1 = k1.data_ptr(), v1.data_ptr(), len1
     a.seg1_blk, a.seg1_cnt, a.mask1 = blk.data_ptr(), cnt.data_ptr(), mask.data_ptr()
@@ -369,17 +373,20 @@ def test_reward_reduce(cuda):
         assert np.array_equal(out.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("d,heads,R", [(128, 2, 16), (512, 8, 16), (1024, 16, 20), (128, 4, 3)])
-def test_attn_group_final_and_partial(cuda, d, heads, R):
+@pytest.mark.parametrize("q_bf16", [0, 1])
+@pytest.mark.parametrize("len1,Lp", [(50, 64), (80, 96)])
+@pytest.mark.parametrize("d,heads,R", [(128, 2, 16), (512, 8, 16), (1024, 16, 20), (128, 4, 3), (256, 8, 32)])
+def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16):
     """MFMA group attention (shared keys, bf16) in both output modes: normalised output (cross
     attention with a padding mask) and running state continued by attn_rows over private keys."""
     L = _lib()
     g = torch.Generator().manual_seed(d + R)
-    nblk, len1 = 4, 50
-    Lp = 64
+    nblk = 4
     G = 7                                   # groups
     M = G * R
     q = (torch.randn(M, d, generator=g) * 0.3).to(cuda)
+    if q_bf16:
+        q = q.bfloat16()
     k1 = torch.randn(nblk, len1, d, generator=g).bfloat16().to(cuda)
     v1 = torch.randn(nblk, len1, d, generator=g).bfloat16().to(cuda)
     vt = torch.full((nblk, d, Lp), float("nan"), dtype=torch.bfloat16, device=cuda)
@@ -387,11 +394,11 @@ def test_attn_group_final_and_partial(cuda, d, heads, R):
     torch.cuda.synchronize()
     assert torch.equal(vt[:, :, :len1], v1.transpose(1, 2)) and vt[:, :, len1:].abs().max().item() == 0
     gblk = torch.randint(0, nblk, (G,), generator=g, dtype=torch.int32)
-    gcnt = torch.tensor([1, 2, 31, 32, 33, 50, 17], dtype=torch.int32)
+    gcnt = torch.tensor([1, 2, 31, 32, 33, len1, 65 if len1 > 65 else 17], dtype=torch.int32)
     blk = gblk.repeat_interleave(R).to(cuda)
     cnt = gcnt.repeat_interleave(R).to(cuda)
     mask = torch.zeros(nblk, len1, dtype=torch.uint8)
-    mask[:, 40:] = 1
+    mask[:, len1 - 10:] = 1
     mask[1, 0] = 1
     mask_d = mask.to(cuda)
 
@@ -407,7 +414,7 @@ def test_attn_group_final_and_partial(cuda, d, heads, R):
     # --- final mode with mask (counts = full length, like cross attention)
     out = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device=cuda)
     a = L.AttnGroupArgs()
-    a.q, a.M, a.d, a.heads, a.rows_per_group = q.data_ptr(), M, d, heads, R
+    a.q, a.M, a.d, a.heads, a.rows_per_group, a.q_bf16 = q.data_ptr(), M, d, heads, R, q_bf16
     a.k, a.vt, a.len, a.len_padded = k1.data_ptr(), vt.data_ptr(), len1, Lp
     a.row_blk, a.row_cnt, a.mask, a.out = blk.data_ptr(), cnt.data_ptr(), mask_d.data_ptr(), out.data_ptr()
     rows_ok = [r for r in range(M) if any(not int(mask[int(blk[r]), j]) for j in range(int(cnt[r])))]
@@ -429,7 +436,7 @@ def test_attn_group_final_and_partial(cuda, d, heads, R):
     v2 = torch.randn(nsteps * M, d, generator=g).bfloat16().to(cuda)
     out2 = torch.empty(M, d, dtype=torch.bfloat16, device=cuda)
     b = L.AttnArgs()
-    b.q, b.M, b.d, b.heads, b.kv_dtype = q.data_ptr(), M, d, heads, L.NMTGAN_BF16
+    b.q, b.M, b.d, b.heads, b.kv_dtype, b.q_op_dtype = q.data_ptr(), M, d, heads, L.NMTGAN_BF16, q_bf16
     b.k2, b.v2, b.step_off, b.n_steps2 = k2.data_ptr(), v2.data_ptr(), step_off.data_ptr(), nsteps
     b.o_init, b.m_init, b.l_init, b.out = o_part.data_ptr(), m_part.data_ptr(), l_part.data_ptr(), out2.data_ptr()
     L.check(L.lib.nmtgan_attn_rows(C.byref(b), L.stream_ptr()))
