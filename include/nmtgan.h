@@ -160,6 +160,12 @@ typedef struct {
   void* out;
   float* o_part; float* m_part; float* l_part;
   int q_bf16;
+  /* Slot form (optional): one workgroup serves `slots` groups that share ONE block of keys (the rollout
+   * groups (b, g), (b, g+1), .. of a sentence: with rollnum 16 two groups fill the 32 MFMA columns).
+   * slot_table[n_entries][2 + 2*slots] int32 on the device: {blk, 0, row0[slots], cnt[slots]}; a slot is
+   * served when 0 <= row0 < M, its rows are row0 .. row0+rows_per_group-1, its key count is cnt (len when
+   * row_cnt is NULL).  row_blk / row_cnt are then only used as "counts present" flags. */
+  const int32_t* slot_table; int slots; int n_entries;
 } nmtgan_attn_group_args;
 int nmtgan_attn_group(const nmtgan_attn_group_args* a, void* stream);
 /* v[nblk*len][d] bf16 -> vt[nblk][d][len_padded] bf16, zero padded */
@@ -305,6 +311,10 @@ typedef struct {
    * decode steps run on `stream`: the conv GEMMs are MFMA-bound, the late decode steps latency/HBM-bound.
    * The library forks/joins the two streams with events (thread-local pool, created once per device);
    * results are identical to the single-stream schedule.  NULL or == stream: single stream. */
+  /* Slot table of nmtgan_attn_group for the rollout steps (optional, see there): entries sorted by the row
+   * index of their first slot, grp_live[s] (HOST, [n_steps+1]) = entries whose first slot is live at step s,
+   * cnt = give_num + 1. */
+  const int32_t* grp_table; int grp_slots; const int32_t* grp_live;
   void* aux_stream;
   int aux_gemm_wgs;                 /* workgroup cap of the persistent GEMMs on aux_stream while decode steps are
                                        still being issued (leaves CUs to the decoder); 0 = default (160) */

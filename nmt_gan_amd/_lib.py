@@ -50,7 +50,8 @@ class AttnGroupArgs(C.Structure):
     _fields_ = [("q", vp), ("M", i32), ("d", i32), ("heads", i32), ("rows_per_group", i32),
                 ("k", vp), ("vt", vp), ("len", i32), ("len_padded", i32),
                 ("row_blk", vp), ("row_cnt", vp), ("mask", vp), ("out", vp),
-                ("o_part", vp), ("m_part", vp), ("l_part", vp), ("q_bf16", i32)]
+                ("o_part", vp), ("m_part", vp), ("l_part", vp), ("q_bf16", i32),
+                ("slot_table", vp), ("slots", i32), ("n_entries", i32)]
 
 
 class SampleArgs(C.Structure):
@@ -101,7 +102,7 @@ class RewardPlan(C.Structure):
                 ("grp_first", vp), ("uniforms", vp), ("use_bias", i32), ("bias_num", f64),
                 ("logits_chunk_rows", i32), ("disc_chunk_rows", i32),
                 ("rewards", vp), ("rollouts", vp), ("p_rows", vp), ("p_base", vp), ("prefix_logits", vp),
-                ("row_g_host", vp), ("aux_stream", vp), ("aux_gemm_wgs", i32), ("aux_min_rows", i32)]
+                ("row_g_host", vp), ("grp_table", vp), ("grp_slots", i32), ("grp_live", vp), ("aux_stream", vp), ("aux_gemm_wgs", i32), ("aux_min_rows", i32)]
 
 
 EXPORTS = {

@@ -33,6 +33,9 @@ struct GroupAttnParams {
   const uint8_t* mask;         // [nblk][L] or NULL
   bf16_t* out;                 // [M][d] normalised output (final mode) or NULL
   float* o_part; float* m_part; float* l_part;   // partial mode: [M][d], [M][heads], [M][heads]
+  // slot form: workgroup e serves `slots` groups of ONE block of keys, table row e =
+  // [blk, 0, row0[slots], cnt[slots]]; a slot is live when 0 <= row0 < M (its R rows are row0 .. row0+R-1)
+  const int32_t* slot_table; int slots;
 };
 
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
@@ -46,18 +49,37 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 // latency-bound (two 32-key tiles per head at T = Ls = 50, ~30 MFMAs), so every global load of a 64-key
 // pair - q, both K tiles, both V^T tiles, the padding mask - is issued before the first MFMA.
 template <int DK, bool QB>
-__global__ __launch_bounds__(256) void attn_group_kernel(GroupAttnParams p) {
+__global__ __launch_bounds__(256, (DK <= 64 ? 3 : 1)) void attn_group_kernel(GroupAttnParams p) {
   constexpr int KS = DK / 16;      // k-steps of the QK^T product
   constexpr int DT = DK / 32;      // 32-row tiles of O^T
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, h2 = lane >> 5;
   const int head = blockIdx.y * 4 + wave;
   if (head >= p.heads) return;
-  const int row0 = blockIdx.x * p.R;
-  const int row = row0 + n;
-  const bool row_ok = n < p.R && row < p.M;
-  const int blk = p.row_blk[row0];
-  const int cnt = p.row_cnt ? p.row_cnt[row0] : p.L;
+  int row, blk, cnt, cnt_lane;
+  bool row_ok;
+  if (p.slot_table) {
+    // several groups of one sentence side by side in the 32 MFMA columns (R = 16: two groups per wave)
+    const int32_t* tab = p.slot_table + (int64_t)blockIdx.x * (2 + 2 * p.slots);
+    blk = tab[0];
+    cnt = 0;
+    for (int sl = 0; sl < p.slots; ++sl) {          // uniform: scalar loads
+      const int r0 = tab[2 + sl];
+      if (r0 >= 0 && r0 < p.M) cnt = max(cnt, p.row_cnt ? tab[2 + p.slots + sl] : p.L);
+    }
+    const int sl = n / p.R;
+    const int r0 = sl < p.slots ? tab[2 + sl] : -1;
+    row_ok = r0 >= 0 && r0 < p.M;
+    row = row_ok ? r0 + n % p.R : 0;
+    cnt_lane = row_ok ? (p.row_cnt ? tab[2 + p.slots + sl] : p.L) : 0;
+  } else {
+    const int row0 = blockIdx.x * p.R;
+    row = row0 + n;
+    row_ok = n < p.R && row < p.M;
+    blk = p.row_blk[row0];
+    cnt = p.row_cnt ? p.row_cnt[row0] : p.L;
+    cnt_lane = cnt;
+  }
   const int d = p.d;
   const uint8_t* mk = p.mask ? p.mask + (int64_t)blk * p.L : nullptr;
 
@@ -117,19 +139,20 @@ __global__ __launch_bounds__(256) void attn_group_kernel(GroupAttnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int kt = (e & 3) + 8 * (e >> 2) + 4 * h2;
-      const bool ok = k0 + kt < cnt && !((bad >> kt) & 1u);
+      const bool ok = k0 + kt < cnt_lane && !((bad >> kt) & 1u);
       sv[e] = ok ? sacc[e] : -INFINITY;
       mx = fmaxf(mx, sv[e]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);
-    if (m_new == -INFINITY) return;             // every key of the tile masked (same for all lanes of a row)
-    const float alpha = __expf(m - m_new);
+    // rows whose keys so far are all masked keep m = -inf: their p and alpha evaluate to 0 via the guard
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __expf(m - m_use);
     float pv[16];
     float ls = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      pv[e] = __expf(sv[e] - m_new);
+      pv[e] = __expf(sv[e] - m_use);
       ls += pv[e];
     }
     ls += __shfl_xor(ls, 32, 64);
@@ -215,13 +238,17 @@ int launch_attn_group(const nmtgan_attn_group_args* a, hipStream_t st) {
   NMTGAN_REQUIRE(a->M > 0 && a->d > 0 && a->heads > 0 && a->d % a->heads == 0, "attn_group: bad M/d/heads");
   NMTGAN_REQUIRE(a->rows_per_group > 0 && a->rows_per_group <= 32 && a->M % a->rows_per_group == 0,
                  "attn_group: rows_per_group must be 1..32 and divide M");
-  NMTGAN_REQUIRE(a->q && a->k && a->vt && a->row_blk, "attn_group: null pointer");
+  NMTGAN_REQUIRE(a->q && a->k && a->vt && (a->row_blk || a->slot_table), "attn_group: null pointer");
+  NMTGAN_REQUIRE(!a->slot_table || (a->slots > 0 && a->slots * a->rows_per_group <= 32 && a->n_entries >= 0),
+                 "attn_group: slot table needs 1 <= slots <= 32 / rows_per_group and n_entries >= 0");
+  if (a->slot_table && a->n_entries == 0) return 0;
   NMTGAN_REQUIRE(a->len > 0 && a->len_padded >= a->len && a->len_padded % 32 == 0, "attn_group: bad key lengths");
   NMTGAN_REQUIRE((a->out != nullptr) != (a->o_part != nullptr), "attn_group: exactly one of out / o_part");
   NMTGAN_REQUIRE(a->out || (a->m_part && a->l_part), "attn_group: partial mode needs m_part and l_part");
   GroupAttnParams p{a->q, a->M, a->d, a->heads, a->rows_per_group, (const bf16_t*)a->k, (const bf16_t*)a->vt, a->len,
-                    a->len_padded, a->row_blk, a->row_cnt, a->mask, (bf16_t*)a->out, a->o_part, a->m_part, a->l_part};
-  dim3 grid(a->M / a->rows_per_group, (a->heads + 3) / 4), block(256);
+                    a->len_padded, a->row_blk, a->row_cnt, a->mask, (bf16_t*)a->out, a->o_part, a->m_part, a->l_part,
+                    a->slot_table, a->slots};
+  dim3 grid(a->slot_table ? a->n_entries : a->M / a->rows_per_group, (a->heads + 3) / 4), block(256);
   const bool qb = a->q_bf16 != 0;
   NMTGAN_REQUIRE(!qb || ((uintptr_t)a->q % 16 == 0 && a->d % 8 == 0), "attn_group: bf16 q must be 16-byte aligned");
 #define NMTGAN_GROUP(DK)                                                                      \

@@ -131,6 +131,7 @@ struct DecAttn {
   int group_R; const void* shVt; int sh_Lp; int64_t sht_layer_stride;
   const void* crossVt; int cross_Lp; int64_t crosst_layer_stride;
   float* o_part; float* m_part; float* l_part;
+  const int32_t* slot_table; int slots; int n_entries;      // several groups of a sentence per workgroup
 };
 
 static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn& c, hipStream_t st) {
@@ -152,6 +153,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       ga.k = at(c.shK, l * c.sh_layer_stride, es); ga.vt = at(c.shVt, l * c.sht_layer_stride, es);
       ga.len = c.len_sh; ga.len_padded = c.sh_Lp; ga.row_blk = c.seg1_blk; ga.row_cnt = c.seg1_cnt;
       ga.o_part = c.o_part; ga.m_part = c.m_part; ga.l_part = c.l_part;
+      ga.slot_table = c.slot_table; ga.slots = c.slots; ga.n_entries = c.n_entries;
       prof::Hint ph(prof::ATTN_SELF);
       NMTGAN_TRY(launch_attn_group(&ga, st));
       nmtgan_attn_args t{};
@@ -184,6 +186,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       ga.q = a.q; ga.q_bf16 = 1; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
       ga.k = at(c.crossK, l * c.cross_layer_stride, es); ga.vt = at(c.crossVt, l * c.crosst_layer_stride, es);
       ga.len = c.Ls; ga.len_padded = c.cross_Lp; ga.row_blk = c.cross_blk; ga.mask = c.x_pad; ga.out = a.ao;
+      ga.slot_table = c.slot_table; ga.slots = c.slots; ga.n_entries = c.n_entries;
       prof::Hint ph(prof::ATTN_CROSS);
       NMTGAN_TRY(launch_attn_group(&ga, st));
     } else {
@@ -613,6 +616,9 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
       c.group_R = b.group_R; c.shVt = b.shVt; c.sh_Lp = b.Tp; c.sht_layer_stride = (int64_t)B * dm * b.Tp;
       c.crossVt = b.crossVt; c.cross_Lp = b.Lsp; c.crosst_layer_stride = (int64_t)B * dm * b.Lsp;
       c.o_part = b.o_part; c.m_part = b.m_part; c.l_part = b.l_part;
+      if (b.group_R > 0 && p->grp_table && p->grp_live && p->grp_slots > 0 && p->grp_slots * b.group_R <= 32) {
+        c.slot_table = p->grp_table; c.slots = p->grp_slots; c.n_entries = p->grp_live[step];
+      }
       NMTGAN_TRY(decoder_pass(g, M, b.act, c, st));
       if (b.fused) {
         NMTGAN_TRY(launch_logits_sample(op, b.act.xo, g->softmax_w, M, V, dm, p->uniforms, p->row_uoff, step, b.tok_cur,

@@ -311,6 +311,9 @@ class Model(object):
             "u": torch.as_tensor(u).to(device=dev, dtype=torch.float32).contiguous(),
             "rewards": torch.zeros((B, T), dtype=torch.float32, device=dev),
         }
+        grp_live = np.ascontiguousarray(plan.grp_live, dtype=np.int32)
+        if plan.grp_slots > 0 and plan.grp_table.shape[0] > 0:
+            t["grp_table"] = self._dev_i32(plan.grp_table)
         live = np.ascontiguousarray(plan.live, dtype=np.int32)
         step_off_h = np.ascontiguousarray(plan.step_off, dtype=np.int64)
         row_g_h = np.ascontiguousarray(plan.row_g, dtype=np.int32)
@@ -331,6 +334,8 @@ class Model(object):
         p.logits_chunk_rows = self.logits_chunk_rows
         p.disc_chunk_rows = self.disc_chunk_rows
         p.rewards = ptr(t["rewards"])
+        if "grp_table" in t:
+            p.grp_table, p.grp_slots, p.grp_live = ptr(t["grp_table"]), int(plan.grp_slots), grp_live.ctypes.data
         if self.overlap:
             if self._aux_stream is None:
                 self._aux_stream = torch.cuda.Stream(device=dev)
@@ -350,7 +355,7 @@ class Model(object):
         g, dsc = self.c_struct, disc.c_struct
         need = lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(dsc), C.byref(p))
         ws = self._workspace(need)
-        return PreparedReward(self, disc, plan, p, t, (live, step_off_h, row_g_h), ws, details)
+        return PreparedReward(self, disc, plan, p, t, (live, step_off_h, row_g_h, grp_live), ws, details)
 
     def get_reward_Obinforced(self, *a, **k):
         raise NotImplementedError("get_reward_Obinforced is never called by the reference drivers (SURVEY section 2 #5)")

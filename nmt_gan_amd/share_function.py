@@ -75,6 +75,9 @@ class RolloutPlan:
     grp_first: np.ndarray     # [B, T-1] int32 first row of (b, g) or -1
     live: np.ndarray          # [n_steps+1] int32
     step_off: np.ndarray      # [n_steps+1] int64
+    grp_slots: int = 0        # groups of one sentence served by one attention workgroup (32 // rollnum)
+    grp_table: np.ndarray = None   # [n_entries, 2 + 2*grp_slots] int32: blk, 0, row0[slots], cnt[slots]
+    grp_live: np.ndarray = None    # [n_steps+1] int32 entries whose first slot is live at step s
 
     @property
     def n_rows(self):
@@ -120,7 +123,34 @@ def build_rollout_plan(y_sample_mask, rollnum, b_offset=0, B_global=None) -> Rol
     step_off = np.zeros(n_steps + 1, np.int64)
     step_off[1:] = np.cumsum(live[1:].astype(np.int64))
     row_uoff = ((row_r * (T - 1) + (row_g - 1)) * B_global + (row_b + b_offset)) * T + row_g
-    return RolloutPlan(B=B, T=T, rollnum=rollnum, lens=lens, row_b=row_b.astype(np.int32),
+    slots, table, tlive = group_slot_table(grp_first, lens, rollnum, live)
+    return RolloutPlan(grp_slots=slots, grp_table=table, grp_live=tlive,
+                       B=B, T=T, rollnum=rollnum, lens=lens, row_b=row_b.astype(np.int32),
                        row_r=row_r.astype(np.int32), row_g=row_g.astype(np.int32),
                        row_lrow=(row_b * T + row_g).astype(np.int32), row_uoff=row_uoff.astype(np.int64),
                        grp_first=grp_first, live=live, step_off=step_off)
+
+
+def group_slot_table(grp_first, lens, rollnum, live):
+    """Slot table of nmtgan_attn_group (include/nmtgan.h): consecutive prefixes g, g+1, .. of ONE sentence
+    share their keys (encoder memory; teacher-forced prefix up to the largest g), so 32 // rollnum of them
+    ride side by side in the 32 MFMA columns of one workgroup.  Entries are sorted by the row index of their
+    first slot (the smallest g = most remaining steps), so the entries live at step s are a prefix."""
+    slots = max(1, 32 // int(rollnum)) if rollnum <= 32 else 0
+    n_steps = live.shape[0] - 1
+    if slots == 0 or grp_first.size == 0:
+        return 0, np.zeros((0, 2), np.int32), np.zeros(n_steps + 1, np.int32)
+    ents = []
+    for b in range(grp_first.shape[0]):
+        gs = [g for g in range(1, int(lens[b])) if grp_first[b, g - 1] >= 0]
+        for i in range(0, len(gs), slots):
+            part = gs[i:i + slots]
+            rows = [int(grp_first[b, g - 1]) for g in part] + [-1] * (slots - len(part))
+            cnts = [g + 1 for g in part] + [0] * (slots - len(part))
+            ents.append([b, 0] + rows + cnts)
+    if not ents:
+        return slots, np.zeros((0, 2 + 2 * slots), np.int32), np.zeros(n_steps + 1, np.int32)
+    table = np.asarray(ents, np.int32)
+    table = table[np.argsort(table[:, 2], kind="stable")]
+    tlive = np.array([(table[:, 2] < live[s]).sum() for s in range(n_steps + 1)], np.int32)
+    return slots, np.ascontiguousarray(table), tlive

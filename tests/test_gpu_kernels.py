@@ -375,7 +375,7 @@ def test_reward_reduce(cuda):
 
 @pytest.mark.parametrize("q_bf16", [0, 1])
 @pytest.mark.parametrize("len1,Lp", [(50, 64), (80, 96)])
-@pytest.mark.parametrize("d,heads,R", [(128, 2, 16), (512, 8, 16), (1024, 16, 20), (128, 4, 3), (256, 8, 32)])
+@pytest.mark.parametrize("d,heads,R", [(128, 2, 16), (512, 8, 16), (1024, 16, 20), (128, 4, 3), (256, 8, 32), (256, 2, 8)])
 def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16):
     """MFMA group attention (shared keys, bf16) in both output modes: normalised output (cross
     attention with a padding mask) and running state continued by attn_rows over private keys."""
@@ -422,7 +422,7 @@ def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16):
     torch.cuda.synchronize()
     for r in rows_ok[::3]:
         err = (out[r].double().cpu() - ref_row(r, True)).abs().max().item()
-        assert err < 3e-2, (r, err)            # bf16 q / p / output rounding
+        assert err < (3e-2 if d // heads <= 64 else 5e-2), (r, err)            # bf16 q / p / output rounding
     # --- partial mode, continued over 3 private keys by attn_rows
     o_part = torch.empty(M, d, device=cuda)
     m_part = torch.empty(M, heads, device=cuda)
@@ -445,4 +445,67 @@ def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16):
         ek = [k2[s * M + r] for s in range(nsteps)]
         ev = [v2[s * M + r] for s in range(nsteps)]
         err = (out2[r].double().cpu() - ref_row(r, False, ek, ev)).abs().max().item()
-        assert err < 3e-2, (r, err)
+        assert err < (3e-2 if d // heads <= 64 else 5e-2), (r, err)
+
+
+@pytest.mark.parametrize("d,heads,R", [(512, 8, 16), (256, 4, 4), (128, 2, 16)])
+def test_attn_group_slot_table(cuda, d, heads, R):
+    """Slot form: 32 // R groups of one sentence per workgroup (per-slot key counts, dead slots, a
+    partially filled entry) must give exactly what the one-group-per-workgroup form gives."""
+    L = _lib()
+    g = torch.Generator().manual_seed(d * R)
+    nblk, len1, Lp = 3, 50, 64
+    slots = 32 // R
+    per_blk = 2 * slots + 1                       # groups per sentence: two full entries + one partial
+    G = nblk * per_blk
+    M = G * R
+    q = (torch.randn(M, d, generator=g) * 0.3).bfloat16().to(cuda)
+    k1 = torch.randn(nblk, len1, d, generator=g).bfloat16().to(cuda)
+    v1 = torch.randn(nblk, len1, d, generator=g).bfloat16().to(cuda)
+    vt = torch.zeros((nblk, d, Lp), dtype=torch.bfloat16, device=cuda)
+    L.check(L.lib.nmtgan_transpose_v(v1.data_ptr(), vt.data_ptr(), nblk, len1, Lp, d, L.stream_ptr()))
+    gblk = torch.arange(nblk, dtype=torch.int32).repeat_interleave(per_blk)
+    gcnt = torch.randint(1, len1 + 1, (G,), generator=g, dtype=torch.int32)
+    gcnt[0], gcnt[1] = 3, 40                      # one entry straddling the 32-key tile boundary
+    blk = gblk.repeat_interleave(R).to(cuda)
+    cnt = gcnt.repeat_interleave(R).to(cuda)
+    mask = torch.zeros(nblk, len1, dtype=torch.uint8)
+    mask[:, 45:] = 1
+    mask[2, 0] = 1
+    mask_d = mask.to(cuda)
+    ents = []
+    for b in range(nblk):
+        gs = [b * per_blk + i for i in range(per_blk)]
+        for i in range(0, per_blk, slots):
+            part = gs[i:i + slots]
+            ents.append([b, 0] + [x * R for x in part] + [-1] * (slots - len(part))
+                        + [int(gcnt[x]) for x in part] + [0] * (slots - len(part)))
+    table = torch.tensor(ents, dtype=torch.int32).to(cuda)
+    M_live = M - 2 * R                            # the last two groups are dead (row0 >= M)
+
+    def run(use_table, final):
+        a = L.AttnGroupArgs()
+        a.q, a.M, a.d, a.heads, a.rows_per_group, a.q_bf16 = q.data_ptr(), M_live, d, heads, R, 1
+        a.k, a.vt, a.len, a.len_padded = k1.data_ptr(), vt.data_ptr(), len1, Lp
+        a.row_blk = blk.data_ptr()
+        out = torch.zeros((M, d), dtype=torch.bfloat16, device=cuda)
+        o_part = torch.zeros(M, d, device=cuda)
+        m_part = torch.zeros(M, heads, device=cuda)
+        l_part = torch.zeros(M, heads, device=cuda)
+        if final:                                 # cross attention: every key, padding mask
+            a.mask, a.out = mask_d.data_ptr(), out.data_ptr()
+        else:
+            a.row_cnt = cnt.data_ptr()
+            a.o_part, a.m_part, a.l_part = o_part.data_ptr(), m_part.data_ptr(), l_part.data_ptr()
+        if use_table:
+            a.slot_table, a.slots, a.n_entries = table.data_ptr(), slots, table.shape[0]
+        L.check(L.lib.nmtgan_attn_group(C.byref(a), L.stream_ptr()))
+        torch.cuda.synchronize()
+        return out, o_part, m_part, l_part
+
+    for final in (True, False):
+        want = run(False, final)
+        got = run(True, final)
+        for w_, g_ in zip(want, got):
+            assert torch.equal(w_[:M_live], g_[:M_live])
+            assert g_[M_live:].abs().max().item() == 0          # dead slots are not written
