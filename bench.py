@@ -240,6 +240,19 @@ def main():
         elapsed = float(tt.item())
     assert bool(torch.isfinite(out).all())
 
+    # the same workload on the single-stream schedule (the discriminator after the last decode step): the
+    # schedule the per-kernel roofline leg below and the committed rocprof summaries are taken on
+    single_ms = None
+    if args.overlap and world == 1:
+        prep1 = prep.with_schedule(overlap=False)
+        prep1.launch()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            prep1.launch()
+        sync()
+        single_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+
     result = {
         "metric": "rollout-scored sentences/sec (rollnum=16, len 50)" if args.config == "c2"
         else "rollout-scored sentences/sec (rollnum=%d, len %d)" % (R, T),
@@ -250,15 +263,20 @@ def main():
                    "rollnum": R, "max_len": T, "vocab": V, "rollouts_per_step": int(prep.plan.n_rows) * world,
                    "sampled_tokens_per_step": int(prep.plan.n_rows + prep.plan.live[1:].sum()) * world,
                    "parallelism": "sentence-sharded x%d, RCCL all-gather of rewards" % world if world > 1 else "single GPU",
-                   "workspace_GiB": round(prep.workspace_bytes / 2 ** 30, 2)},
+                   "workspace_GiB": round(prep.workspace_bytes / 2 ** 30, 2),
+                   "schedule": "two-stream: discriminator scoring of finished rollouts overlaps the remaining decode "
+                               "steps" if args.overlap else "single stream"},
     }
+    if single_ms is not None:
+        result["single_stream_ms_per_step"] = round(single_ms, 2)
 
     if rank == 0 and world == 1 and not args.no_roofline:
         ncls = _lib.lib.nmtgan_profile_classes()
         ms = (C.c_double * ncls)()
         cnt = (C.c_int64 * ncls)()
+        prof_prep = prep.with_schedule(overlap=False) if args.overlap else prep
         _lib.lib.nmtgan_profile_start()
-        step()
+        prof_prep.launch()
         _lib.check(_lib.lib.nmtgan_profile_stop(ms, cnt, ncls), "profile_stop")
         work = algorithmic_work(cfg, prep.plan, Bl, x.shape[1], 2 if args.precision == "bf16" else 4)
         rows = {}
@@ -284,9 +302,12 @@ def main():
                               "traffic": committed_traffic(top, args.config, args.precision),
                               "algorithmic_per_launch": round(r["algorithmic_per_step"] / r["launches"]),
                               "launches": r["launches"], "avg_launch_us": r["avg_us"],
-                              "note": "HIP events around every launch of one extra (untimed) step; achieved = "
-                                      "algorithmic work of the class / summed launch time; traffic = HBM bytes "
-                                      "per launch from the committed PMC summary profiles/r1_c2_bf16_hbm_traffic.json"}
+                              "note": "HIP events around every launch of one extra (untimed) step on the SINGLE-STREAM "
+                                      "schedule (kernels in isolation; same schedule as `bench.py --overlap 0`, whose "
+                                      "rocprofv3 --kernel-trace --stats summary is committed under profiles/); "
+                                      "achieved = algorithmic work of the class / summed launch time; traffic = HBM "
+                                      "bytes per launch from the committed PMC summary "
+                                      "profiles/r1_c2_bf16_hbm_traffic.json"}
         result["roofline_all"] = rows
         result["profiled_step_ms"] = round(float(sum(ms)), 2)
 

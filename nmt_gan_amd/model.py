@@ -374,6 +374,19 @@ class PreparedReward(object):
     def workspace_bytes(self):
         return int(self.ws.numel())
 
+    def with_schedule(self, overlap):
+        """Same prepared call (same tensors, workspace and plan) on the other schedule: overlap=False puts
+        the whole path on the current stream, True hands the discriminator to the model's auxiliary stream."""
+        cplan = type(self.cplan).from_buffer_copy(self.cplan)   # pointers still borrowed from self
+        if overlap:
+            if self.model._aux_stream is None:
+                self.model._aux_stream = torch.cuda.Stream(device=self.model.device)
+            cplan.aux_stream = self.model._aux_stream.cuda_stream
+        else:
+            cplan.aux_stream = None
+        return PreparedReward(self.model, self.disc, self.plan, cplan, self.tensors, self.host_tables, self.ws,
+                              self.details)
+
     def launch(self):
         g, dsc = self.model.c_struct, self.disc.c_struct
         check(lib.nmtgan_rollout_reward(C.byref(g), C.byref(dsc), C.byref(self.cplan), ptr(self.ws), self.ws.numel(),
