@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnmtgan_hip.so")
+LIB_PATH = os.environ.get("NMTGAN_LIB") or os.path.join(_HERE, "libnmtgan_hip.so")   # NMTGAN_LIB: another build of the same ABI
 
 NMTGAN_BF16, NMTGAN_F32 = 0, 1
 EPI_LINEAR, EPI_CONVMAX = 0, 1

@@ -73,6 +73,7 @@ class Model(object):
         self.disc_chunk_rows = 8192
         # two-stream schedule of get_reward (discriminator scoring of finished rollouts overlaps the decode steps)
         self.overlap = True
+        self.group_slots = True        # 32 // rollnum prefix groups of a sentence per attention workgroup
         self.aux_gemm_wgs = 0          # 0 = library default
         self.aux_min_rows = 0
         self._aux_stream = None
@@ -312,7 +313,7 @@ class Model(object):
             "rewards": torch.zeros((B, T), dtype=torch.float32, device=dev),
         }
         grp_live = np.ascontiguousarray(plan.grp_live, dtype=np.int32)
-        if plan.grp_slots > 0 and plan.grp_table.shape[0] > 0:
+        if self.group_slots and plan.grp_slots > 0 and plan.grp_table.shape[0] > 0:
             t["grp_table"] = self._dev_i32(plan.grp_table)
         live = np.ascontiguousarray(plan.live, dtype=np.int32)
         step_off_h = np.ascontiguousarray(plan.step_off, dtype=np.int64)

@@ -77,6 +77,32 @@ def test_fullsize_deterministic(c2):
     assert np.array_equal(r2, c2["r"])
 
 
+def test_fullsize_schedules_agree(c2):
+    """The two-stream schedule (discriminator on the auxiliary stream while decode steps still run; the
+    default) and the single-stream schedule give bit-identical rollouts, scores and rewards; so does the
+    one-group-per-workgroup attention (no slot table)."""
+    m = c2["model"]
+    assert m.overlap
+    try:
+        m.overlap = False
+        r1 = m.get_reward(c2["x"], c2["xp"], c2["y"], c2["mask"], R, c2["disc"], max_len=T, bias_num=0.6,
+                          uniforms=c2["u"], return_details=True)
+        d1 = m.last_details
+    finally:
+        m.overlap = True
+    assert np.array_equal(d1["rollouts"], c2["det"]["rollouts"])
+    assert np.array_equal(d1["p_rows"], c2["det"]["p_rows"])
+    assert np.array_equal(r1, c2["r"])
+    try:
+        m.group_slots = False
+        r2 = m.get_reward(c2["x"], c2["xp"], c2["y"], c2["mask"], R, c2["disc"], max_len=T, bias_num=0.6,
+                          uniforms=c2["u"], return_details=True)
+    finally:
+        m.group_slots = True
+    assert np.array_equal(m.last_details["rollouts"], c2["det"]["rollouts"])
+    assert np.array_equal(r2, c2["r"])
+
+
 def test_fullsize_shard_invariance(c2):
     """Sentences 16..39 computed as their own shard (uniforms addressed by global sentence id) give the
     rows of the unsharded call: identical tokens, rewards equal up to the kernel-choice dependent

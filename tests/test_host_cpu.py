@@ -108,6 +108,27 @@ def test_rollout_plan_invariants():
         bad = mask.copy()
         bad[0, 3] = 0
         N.build_rollout_plan(bad, R)
+    # attention slot table: 32 // R groups of ONE sentence per entry, every group exactly once, key count
+    # g + 1, entries sorted by their first row so the entries live at step s are the prefix [0, grp_live[s])
+    S = p.grp_slots
+    assert S == 32 // R and p.grp_table.shape[1] == 2 + 2 * S
+    seen = []
+    for e in p.grp_table:
+        b, rows, cnts = int(e[0]), e[2:2 + S], e[2 + S:]
+        assert rows[0] >= 0
+        for r0, c in zip(rows, cnts):
+            if r0 >= 0:
+                assert p.row_b[r0] == b and p.row_g[r0] + 1 == c and r0 % R == 0
+                seen.append(int(r0))
+        live_rows = rows[rows >= 0]
+        assert (np.diff(live_rows) > 0).all()                       # slot 0 = smallest g = lives longest
+    assert sorted(seen) == list(range(0, p.n_rows, R))
+    assert (np.diff(p.grp_table[:, 2]) > 0).all()
+    for s in range(p.n_steps + 1):
+        n = p.grp_live[s]
+        assert (p.grp_table[:n, 2] < p.live[s]).all() and (p.grp_table[n:, 2] >= p.live[s]).all()
+    big = N.build_rollout_plan(mask, 40)                            # rollnum > 32: no table, plain form
+    assert big.grp_slots == 0 and big.grp_table.shape[0] == 0
 
 
 _GLOO_WORKER = r'''

@@ -16,6 +16,12 @@ SHAPES = [  # name, M, N, K, conv(P,T,E) or None, out_f32
     ("logits M4096  N32000 K512", 4096, 32000, 512, None, 1),
     ("logits M16384 N32000 K512", 16384, 32000, 512, None, 1),
     ("conv w1  S4096", 4096 * 50, 110, 512, (50, 50, 512), 1),
+    ("conv w5  S4096", 4096 * 46, 150, 5 * 512, (46, 50, 512), 1),
+    ("conv w9  S4096", 4096 * 42, 190, 9 * 512, (42, 50, 512), 1),
+    ("conv w17 S4096", 4096 * 34, 270, 17 * 512, (34, 50, 512), 1),
+    ("conv w21 S4096", 4096 * 30, 310, 21 * 512, (30, 50, 512), 1),
+    ("conv w29 S4096", 4096 * 22, 390, 29 * 512, (22, 50, 512), 1),
+    ("conv w45 S4096", 4096 * 6, 550, 45 * 512, (6, 50, 512), 1),
     ("conv w13 S4096", 4096 * 38, 230, 13 * 512, (38, 50, 512), 1),
     ("conv w25 S4096", 4096 * 26, 350, 25 * 512, (26, 50, 512), 1),
     ("conv w37 S4096", 4096 * 14, 470, 37 * 512, (14, 50, 512), 1),
