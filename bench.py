@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--disc-chunk", type=int, default=None)
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1],
                     help="1: two-stream schedule (discriminator scoring of finished rollouts overlaps the decode steps)")
+    ap.add_argument("--no-single-stream-leg", action="store_true",
+                    help="skip the extra timing of the same workload on the single-stream schedule")
     ap.add_argument("--aux-wgs", type=int, default=0)
     ap.add_argument("--aux-min-rows", type=int, default=0)
     args = ap.parse_args()
@@ -243,7 +245,7 @@ def main():
     # the same workload on the single-stream schedule (the discriminator after the last decode step): the
     # schedule the per-kernel roofline leg below and the committed rocprof summaries are taken on
     single_ms = None
-    if args.overlap and world == 1:
+    if args.overlap and world == 1 and not args.no_single_stream_leg:
         prep1 = prep.with_schedule(overlap=False)
         prep1.launch()
         sync()
