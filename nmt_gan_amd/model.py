@@ -293,7 +293,7 @@ class Model(object):
         return rewards
 
     def prepare_reward(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, b_offset=0, B_global=None,
-                       return_details=False):
+                       return_details=False, own_workspace=False, stream=None):
         """Host half of get_reward: build the rollout plan, upload ids/tables, size the workspace.
         Returns a PreparedReward whose launch() only enqueues device work (inputs resident in HBM)."""
         dev = self.device
@@ -355,8 +355,17 @@ class Model(object):
             p.p_base, p.prefix_logits = ptr(details["p_base"]), ptr(details["prefix_logits"])
         g, dsc = self.c_struct, disc.c_struct
         need = lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(dsc), C.byref(p))
-        ws = self._workspace(need)
-        return PreparedReward(self, disc, plan, p, t, (live, step_off_h, row_g_h, grp_live), ws, details)
+        if own_workspace:              # several prepared calls alive at once (sub-batches on their own streams)
+            if need == 0:
+                raise _lib.NmtGanError("workspace query failed: " + lib.nmtgan_last_error().decode())
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            if self.overlap:
+                keep_aux = torch.cuda.Stream(device=dev)
+                p.aux_stream = keep_aux.cuda_stream
+                t["_aux_stream"] = keep_aux
+        else:
+            ws = self._workspace(need)
+        return PreparedReward(self, disc, plan, p, t, (live, step_off_h, row_g_h, grp_live), ws, details, stream)
 
     def get_reward_Obinforced(self, *a, **k):
         raise NotImplementedError("get_reward_Obinforced is never called by the reference drivers (SURVEY section 2 #5)")
@@ -367,9 +376,10 @@ class PreparedReward(object):
     path on the current stream (no allocation, no synchronisation) and returns the device tensor
     [B, T] the rewards are written to."""
 
-    def __init__(self, model, disc, plan, cplan, tensors, host_tables, ws, details):
+    def __init__(self, model, disc, plan, cplan, tensors, host_tables, ws, details, stream=None):
         self.model, self.disc, self.plan, self.cplan = model, disc, plan, cplan
         self.tensors, self.host_tables, self.ws, self.details = tensors, host_tables, ws, details
+        self.stream = stream           # torch.cuda.Stream to enqueue on (None: the current stream)
 
     @property
     def workspace_bytes(self):
@@ -386,12 +396,13 @@ class PreparedReward(object):
         else:
             cplan.aux_stream = None
         return PreparedReward(self.model, self.disc, self.plan, cplan, self.tensors, self.host_tables, self.ws,
-                              self.details)
+                              self.details, self.stream)
 
     def launch(self):
         g, dsc = self.model.c_struct, self.disc.c_struct
+        st = _lib.stream_ptr() if self.stream is None else self.stream.cuda_stream
         check(lib.nmtgan_rollout_reward(C.byref(g), C.byref(dsc), C.byref(self.cplan), ptr(self.ws), self.ws.numel(),
-                                        _lib.stream_ptr()), "nmtgan_rollout_reward")
+                                        st), "nmtgan_rollout_reward")
         return self.tensors["rewards"]
 
 
