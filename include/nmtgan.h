@@ -349,7 +349,9 @@ int nmtgan_teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, co
  * 0 other, 1 gemm_proj (QKV/out/cross projections), 2 gemm_ffn, 3 gemm_logits, 4 gemm_conv
  * (discriminator conv+BN+ReLU+max), 5 gemm_highway, 6 attn_self_step, 7 attn_cross_step,
  * 8 attn_prefill (encoder + teacher-forced pass), 9 sampler, 10 add_layernorm, 11 embed,
- * 12 disc_small (gather/cast/gate/head/reduce).  Allocates events: never use inside timed runs.
+ * 12 disc_small (gather/cast/gate/head/reduce), 13 attn_self_private (the per-row pass over the private
+ * suffix keys of a rollout step when the shared prefix went through nmtgan_attn_group; class 6 then holds
+ * only the shared-prefix pass).  Allocates events: never use inside timed runs.
  */
 int nmtgan_profile_classes(void);
 int nmtgan_profile_start(void);

@@ -161,6 +161,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       t.k2 = at(c.prK, l * c.pr_layer_stride, es); t.v2 = at(c.prV, l * c.pr_layer_stride, es);
       t.step_off = c.step_off; t.n_steps2 = c.n_steps2;
       t.o_init = c.o_part; t.m_init = c.m_part; t.l_init = c.l_part; t.out = a.ao;
+      prof::Hint ph2(prof::ATTN_SELF_PRIVATE);
       NMTGAN_TRY(launch_attn_rows(&t, st));
     } else {
       nmtgan_attn_args t{};
