@@ -126,7 +126,7 @@ def cpu_baseline(cfg, Wg, Wd, x, y, seed_u):
     mask = np.ones_like(ys, dtype=np.float32)
     xp = O.extend_sentence_to_maxlen(xs, T)
     u = np.random.default_rng(seed_u).random((1, T - 1, Bc, T), dtype=np.float32)
-    stride = 8 if cfg["d"] >= 512 else 4
+    stride = 3 if cfg["d"] >= 512 else 2
     gs = list(range(T - 1, 0, -stride))                # stratified prefixes: 1, 1+stride, ... sampled steps (~10-30 s)
     pts = []
     t_all = time.perf_counter()
