@@ -320,7 +320,9 @@ def main():
                               "note": "HIP events around every launch of one extra (untimed) step on the SINGLE-STREAM "
                                       "schedule (kernels in isolation; same schedule as `bench.py --overlap 0`, whose "
                                       "rocprofv3 --kernel-trace --stats summary is committed under profiles/); "
-                                      "achieved = algorithmic work of the class / summed launch time; traffic = HBM "
+                                      "achieved = algorithmic work of the class / summed launch time (a launch = one library GEMM "
+                                      "call: a conv call split into 256-column panels + remainder shows as two kernels "
+                                      "in rocprof, 201 kernels per step for these 172 launches, same total); traffic = HBM "
                                       "bytes per launch from the committed PMC summary "
                                       "profiles/r1_c2_bf16_hbm_traffic.json"}
         result["roofline_all"] = rows
