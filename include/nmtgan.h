@@ -77,6 +77,8 @@ typedef struct {
   const float* shift;        /* [N] */
   float* pooled;
   int64_t ld_pool;
+  int64_t ldw;               /* elements per Wt row; 0 = K.  > K selects a column slice of a wider matrix (the taps
+                                [k, w) of a conv filter bank: Wt + k*E, K = (w-k)*E, ldw = w*E) */
 } nmtgan_gemm_args;
 int nmtgan_gemm(const nmtgan_gemm_args* a, void* stream);
 
@@ -320,6 +322,10 @@ typedef struct {
                                        still being issued (leaves CUs to the decoder); 0 = default (160) */
   int aux_min_rows;                 /* finished rollouts are handed to aux_stream in batches of at least this
                                        many rows; 0 = default (4096) */
+  int conv_bucket_taps;             /* partial-window reuse in the discriminator (needs row_g_host): a conv window that
+                                       straddles a rollout's give point takes the sum over its leading prefix taps, in
+                                       blocks of this many taps, from one pass over y_sample and only multiplies the
+                                       rest.  0 = default (8), < 0 = off (every such window is multiplied in full) */
 } nmtgan_reward_plan;
 size_t nmtgan_rollout_reward_workspace_bytes(const nmtgan_generator* g, const nmtgan_discriminator* d,
                                              const nmtgan_reward_plan* plan);

@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
                 ("lda", i64), ("a_group", i32), ("a_group_stride", i64),
                 ("bias", vp), ("relu", i32), ("n_seg", i32), ("seg_width", i32),
                 ("out", vp * 3), ("ldo", i64 * 3), ("out_f32", i32 * 3), ("seg_scale", f32 * 3),
-                ("scale", vp), ("shift", vp), ("pooled", vp), ("ld_pool", i64)]
+                ("scale", vp), ("shift", vp), ("pooled", vp), ("ld_pool", i64), ("ldw", i64)]
 
 
 class EmbedArgs(C.Structure):
@@ -102,7 +102,7 @@ class RewardPlan(C.Structure):
                 ("grp_first", vp), ("uniforms", vp), ("use_bias", i32), ("bias_num", f64),
                 ("logits_chunk_rows", i32), ("disc_chunk_rows", i32),
                 ("rewards", vp), ("rollouts", vp), ("p_rows", vp), ("p_base", vp), ("prefix_logits", vp),
-                ("row_g_host", vp), ("grp_table", vp), ("grp_slots", i32), ("grp_live", vp), ("aux_stream", vp), ("aux_gemm_wgs", i32), ("aux_min_rows", i32)]
+                ("row_g_host", vp), ("grp_table", vp), ("grp_slots", i32), ("grp_live", vp), ("aux_stream", vp), ("aux_gemm_wgs", i32), ("aux_min_rows", i32), ("conv_bucket_taps", i32)]
 
 
 EXPORTS = {

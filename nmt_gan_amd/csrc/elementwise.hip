@@ -221,6 +221,47 @@ __global__ void pool_init_kernel(const float* pm, const int32_t* row_b, const in
   const int r = (int)(i / Fp4), c = (int)(i % Fp4);
   pooled[i] = reinterpret_cast<const float4*>(pm)[((int64_t)row_b[r] * T + row_g[r]) * Fp4 + c];
 }
+// partial-window reuse of the discriminator conv (pipeline.hip): S += prev (prefix sums over tap blocks), and the
+// finish of one bucket of windows: pooled[m][f] = max(pooled[m][f], max_q relu((raw[m*nq+q][f] + S[(b_m*P + pa+q)][f])
+// * scale[f] + shift[f])) - the conv bias + BN + ReLU + max-over-time of cnn_discriminator.py:94-105, 469 applied to
+// (taps computed from the rollout) + (taps taken from y_sample)
+__global__ void add_inplace_kernel(float* dst, const float* src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+int launch_add_inplace(float* dst, const float* src, int64_t n, hipStream_t st) {
+  prof::Scope prof_scope(prof::DISC_SMALL, st);
+  if (n == 0) return 0;
+  NMTGAN_REQUIRE(dst && src && n > 0, "add_inplace: bad arguments");
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n);
+  NMTGAN_CHECK_LAUNCH("add_inplace");
+  return 0;
+}
+__global__ void bucket_finish_kernel(const float* raw, const float* S, const int32_t* row_b, int rows, int nq, int N,
+                                     int P, int pa, const float* scale, const float* shift, float* pooled,
+                                     int64_t ld_pool) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = blockIdx.y;
+  if (f >= N || m >= rows) return;
+  const float sc = scale[f], sh = shift[f];
+  const float* r = raw + (int64_t)m * nq * N + f;
+  const float* s = S + ((int64_t)row_b[m] * P + pa) * N + f;
+  float mx = pooled[(int64_t)m * ld_pool + f];
+  for (int q = 0; q < nq; ++q) mx = fmaxf(mx, (r[(int64_t)q * N] + s[(int64_t)q * N]) * sc + sh);   // relu: pooled >= 0
+  pooled[(int64_t)m * ld_pool + f] = mx;
+}
+int launch_bucket_finish(const float* raw, const float* S, const int32_t* row_b, int rows, int nq, int N, int P, int pa,
+                         const float* scale, const float* shift, float* pooled, int64_t ld_pool, hipStream_t st) {
+  prof::Scope prof_scope(prof::DISC_SMALL, st);
+  if (rows == 0) return 0;
+  NMTGAN_REQUIRE(raw && S && row_b && scale && shift && pooled && nq > 0 && N > 0 && pa >= 0 && pa + nq <= P,
+                 "bucket_finish: bad arguments");
+  hipLaunchKernelGGL(bucket_finish_kernel, dim3((N + 127) / 128, rows), dim3(128), 0, st, raw, S, row_b, rows, nq, N, P,
+                     pa, scale, shift, pooled, ld_pool);
+  NMTGAN_CHECK_LAUNCH("bucket_finish");
+  return 0;
+}
+
 int launch_pool_init(const float* pm, const int32_t* row_b, const int32_t* row_g, int rows, int T, int Fp,
                      float* pooled, hipStream_t st) {
   prof::Scope prof_scope(prof::DISC_SMALL, st);

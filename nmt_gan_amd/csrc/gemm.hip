@@ -980,7 +980,8 @@ int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st) {
   p.lda_b = a->lda * es;
   p.a_group = a->a_group > 0 ? a->a_group : 0;
   p.a_group_stride_b = a->a_group_stride * es;
-  p.ldw_b = (int64_t)a->K * es;
+  NMTGAN_REQUIRE(a->ldw == 0 || (a->ldw >= a->K && (a->ldw * es) % 16 == 0), "gemm: ldw must be 0 or >= K, 16-byte rows");
+  p.ldw_b = (a->ldw > 0 ? a->ldw : (int64_t)a->K) * es;
   p.kbytes = a->K * es;
   p.k_inner = 1; p.k_step = BKB; p.k_jump = BKB;
   static const bool tap_order = [] { const char* e = getenv("NMTGAN_CONV_TAPORDER"); return !e || atoi(e) != 0; }();

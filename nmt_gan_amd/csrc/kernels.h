@@ -35,6 +35,9 @@ int launch_prefix_max(const float* C, float* pm, int B, int T, int Fp, int n_wid
                       const int* n_filters, hipStream_t st);
 int launch_pool_init(const float* pm, const int32_t* row_b, const int32_t* row_g, int rows, int T, int Fp,
                      float* pooled, hipStream_t st);
+int launch_add_inplace(float* dst, const float* src, int64_t n, hipStream_t st);
+int launch_bucket_finish(const float* raw, const float* S, const int32_t* row_b, int rows, int nq, int N, int P, int pa,
+                         const float* scale, const float* shift, float* pooled, int64_t ld_pool, hipStream_t st);
 int launch_highway_gate(const float* H, const float* o, const float* t, float* out, int64_t n, hipStream_t st);
 int launch_disc_head(const float* feat_t, const float* feat_s, const int32_t* src_row, int M, int Fp,
                      const float* head_w, const float* head_b, float* p_real, float* probs2, hipStream_t st);

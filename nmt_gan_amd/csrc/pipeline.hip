@@ -266,9 +266,30 @@ static void carve_disc(Arena& ar, const nmtgan_discriminator* d, int chunk, Disc
 struct PrefixReuse { const float* pm; const int32_t* row_b; const int32_t* row_g; const int32_t* row_g_host; };
 static const int REUSE_ROWS = [] { const char* e = getenv("NMTGAN_REUSE_ROWS"); return e && atoi(e) > 0 ? atoi(e) : 4096; }();   // granularity at which the first computed window is chosen
 
+// Windows that STRADDLE the give point (p < g < p + w) start with g - p tokens of y_sample.  Their taps are cut
+// into blocks of `delta`: a window whose first c*delta taps lie in the prefix takes that part of its sum from
+// S[w][c][b][p] = sum_{j < c*delta} E[y_b[p+j]] . W_w[j]  (one pass over y_sample per get_reward, prefix sums
+// over tap blocks) and only multiplies the taps from c*delta on with the rollout's tokens: a plain GEMM over the
+// windows p in (g - (c+1)*delta, g - c*delta] with K = (w - c*delta)*E into `raw`, then bucket_finish adds S,
+// applies BN + ReLU and folds the max into the pooled features.  Windows closer than delta to the give point (and
+// those behind it) keep the fused conv + max GEMM with all their taps.  -28 % conv FLOPs at T = 50, delta = 8.
+constexpr int BUCKET_MAX_C = 16;
+struct BucketReuse {
+  int delta;
+  void* ye;                                    // y_sample sentence image [B*T][E], op dtype
+  float* S; float* raw;
+  int64_t s_off[NMTGAN_MAX_WIDTHS][BUCKET_MAX_C];   // float offset of S[width i][c], c = 1..; [i][0] unused
+};
+static int bucket_delta(const nmtgan_reward_plan* p) {          // NMTGAN_CONV_BUCKET overrides the plan field
+  static const int env = [] { const char* e = getenv("NMTGAN_CONV_BUCKET"); return e ? atoi(e) : -1000; }();
+  if (env != -1000) return env;
+  return p->conv_bucket_taps == 0 ? 8 : p->conv_bucket_taps;
+}
+
 // highway features of `rows` sentences ids[rows][T] -> feat[rows][Fp]
 static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* ids,
-                               int rows, float* feat, DiscBufs& b, hipStream_t st, const PrefixReuse* reuse = nullptr) {
+                               int rows, float* feat, DiscBufs& b, hipStream_t st, const PrefixReuse* reuse = nullptr,
+                               const BucketReuse* bk = nullptr) {
   const int T = d->max_len, E = d->dim_word, Fp = d->Fp, op = d->op_dtype;
   NMTGAN_TRY(launch_disc_embed(tw.emb, op, &tw == &d->src ? d->vocab_s : d->vocab, ids, (int64_t)rows * T, E, b.e, st));
   if (reuse) {
@@ -276,31 +297,66 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
   } else if (hipMemsetAsync(b.pooled, 0, (size_t)rows * Fp * sizeof(float), st) != hipSuccess) {
     NMTGAN_FAIL(-3, "disc: memset failed");
   }
+  auto conv_max = [&](int i, int s0, int s1, int p0, int col) -> int {      // fused conv + BN + ReLU + max, all taps
+    const int w = d->widths[i], P = T - w + 1 - p0;
+    if (P <= 0 || s1 <= s0) return 0;
+    nmtgan_gemm_args a{};
+    a.op_dtype = op; a.epilogue = NMTGAN_EPI_CONVMAX;
+    a.A = at(b.e, ((int64_t)s0 * T + p0) * E, dtype_size(op)); a.Wt = tw.conv_w[i];
+    a.M = (s1 - s0) * P; a.N = d->n_filters[i]; a.K = w * E;
+    a.lda = E; a.a_group = P; a.a_group_stride = (int64_t)T * E;
+    a.scale = tw.conv_scale[i]; a.shift = tw.conv_shift[i]; a.pooled = b.pooled + (int64_t)s0 * Fp + col; a.ld_pool = Fp;
+    prof::Hint ph(prof::GEMM_CONV);
+    return launch_gemm(&a, st);
+  };
   int col = 0;
   for (int i = 0; i < d->n_widths; ++i) {
     const int w = d->widths[i];
+    const bool buckets = reuse && bk && bk->delta > 0 && w > bk->delta;
     // sub-ranges of REUSE_ROWS rows; p0 = first window that can contain a sampled token of any row of the
     // sub-range (p + w > smallest give_num); neighbours with the same p0 are merged into one GEMM
     for (int s0 = 0; s0 < rows;) {
-      auto first_window = [&](int lo) {
-        if (!reuse) return 0;
+      auto g_low = [&](int lo) {
         int g_min = T;
         for (int r = lo; r < rows && r < lo + REUSE_ROWS; ++r) g_min = reuse->row_g_host[r] < g_min ? reuse->row_g_host[r] : g_min;
+        return g_min;
+      };
+      auto first_window = [&](int lo) {
+        if (!reuse) return 0;
+        const int g_min = g_low(lo);
         return g_min - w + 1 > 0 ? g_min - w + 1 : 0;
       };
-      const int p0 = first_window(s0);
       int s1 = s0 + REUSE_ROWS < rows ? s0 + REUSE_ROWS : rows;
       if (!reuse) s1 = rows;
-      while (s1 < rows && first_window(s1) == p0) s1 = s1 + REUSE_ROWS < rows ? s1 + REUSE_ROWS : rows;
-      const int P = T - w + 1 - p0;
-      nmtgan_gemm_args a{};
-      a.op_dtype = op; a.epilogue = NMTGAN_EPI_CONVMAX;
-      a.A = at(b.e, ((int64_t)s0 * T + p0) * E, dtype_size(op)); a.Wt = tw.conv_w[i];
-      a.M = (s1 - s0) * P; a.N = d->n_filters[i]; a.K = w * E;
-      a.lda = E; a.a_group = P; a.a_group_stride = (int64_t)T * E;
-      a.scale = tw.conv_scale[i]; a.shift = tw.conv_shift[i]; a.pooled = b.pooled + (int64_t)s0 * Fp + col; a.ld_pool = Fp;
-      prof::Hint ph(prof::GEMM_CONV);
-      NMTGAN_TRY(launch_gemm(&a, st));
+      if (!buckets) {
+        const int p0 = first_window(s0);
+        while (s1 < rows && first_window(s1) == p0) s1 = s1 + REUSE_ROWS < rows ? s1 + REUSE_ROWS : rows;
+        NMTGAN_TRY(conv_max(i, s0, s1, p0, col));
+      } else {
+        const int dl = bk->delta, g_lo = g_low(s0), es = dtype_size(op), N = d->n_filters[i], Pw = T - w + 1;
+        NMTGAN_TRY(conv_max(i, s0, s1, g_lo - dl + 1 > 0 ? g_lo - dl + 1 : 0, col));     // windows within delta of g, or behind
+        for (int c = 1; c * dl <= w - 1 && c < BUCKET_MAX_C; ++c) {
+          int pa = g_lo - (c + 1) * dl + 1, pb = g_lo - c * dl;
+          if (pa < g_lo - w + 1) pa = g_lo - w + 1;                   // windows below hold no sampled token
+          if (pa < 0) pa = 0;
+          if (pb > T - w) pb = T - w;
+          if (pb < pa) continue;
+          const int nq = pb - pa + 1;
+          nmtgan_gemm_args a{};
+          a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
+          a.A = at(b.e, ((int64_t)s0 * T + pa + c * dl) * E, es); a.Wt = at(tw.conv_w[i], (int64_t)c * dl * E, es);
+          a.M = (s1 - s0) * nq; a.N = N; a.K = (w - c * dl) * E; a.ldw = (int64_t)w * E;
+          a.lda = E; a.a_group = nq; a.a_group_stride = (int64_t)T * E;
+          a.n_seg = 1; a.seg_width = N; a.out[0] = bk->raw; a.ldo[0] = N; a.out_f32[0] = 1; a.seg_scale[0] = 1.f;
+          {
+            prof::Hint ph(prof::GEMM_CONV);
+            NMTGAN_TRY(launch_gemm(&a, st));
+          }
+          prof::Hint ph(prof::GEMM_CONV);
+          NMTGAN_TRY(launch_bucket_finish(bk->raw, bk->S + bk->s_off[i][c], reuse->row_b + s0, s1 - s0, nq, N, Pw, pa,
+                                          tw.conv_scale[i], tw.conv_shift[i], b.pooled + (int64_t)s0 * Fp + col, Fp, st));
+        }
+      }
       s0 = s1;
     }
     col += d->n_filters[i];
@@ -313,6 +369,33 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
     NMTGAN_TRY(dense1(op, b.pooled_op, Fp, rows, Fp, Fp, wt, b.ht, Fp, 1, 1.f, 0, st));
   }
   return launch_highway_gate(b.pooled, b.ho, b.ht, feat, (int64_t)rows * Fp, st);
+}
+
+// S tables of the partial-window reuse from the y_sample image: per width and tap block c one GEMM over the
+// taps [(c-1)*delta, c*delta) of every window, then prefix sums over c
+static int bucket_tables(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* y, int B,
+                         const BucketReuse& bk, hipStream_t st) {
+  const int T = d->max_len, E = d->dim_word, op = d->op_dtype, es = dtype_size(op), dl = bk.delta;
+  NMTGAN_TRY(launch_disc_embed(tw.emb, op, d->vocab, y, (int64_t)B * T, E, bk.ye, st));
+  for (int i = 0; i < d->n_widths; ++i) {
+    const int w = d->widths[i], N = d->n_filters[i], Pw = T - w + 1;
+    if (w <= dl) continue;
+    for (int c = 1; c * dl <= w - 1 && c < BUCKET_MAX_C; ++c) {
+      float* Sc = bk.S + bk.s_off[i][c];
+      nmtgan_gemm_args a{};
+      a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
+      a.A = at(bk.ye, (int64_t)(c - 1) * dl * E, es); a.Wt = at(tw.conv_w[i], (int64_t)(c - 1) * dl * E, es);
+      a.M = B * Pw; a.N = N; a.K = dl * E; a.ldw = (int64_t)w * E;
+      a.lda = E; a.a_group = Pw; a.a_group_stride = (int64_t)T * E;
+      a.n_seg = 1; a.seg_width = N; a.out[0] = Sc; a.ldo[0] = N; a.out_f32[0] = 1; a.seg_scale[0] = 1.f;
+      {
+        prof::Hint ph(prof::GEMM_CONV);
+        NMTGAN_TRY(launch_gemm(&a, st));
+      }
+      if (c > 1) NMTGAN_TRY(launch_add_inplace(Sc, bk.S + bk.s_off[i][c - 1], (int64_t)B * Pw * N, st));
+    }
+  }
+  return 0;
 }
 
 // C[b*T + p][Fp] = relu(bn(conv)) of every window p of rows sentences (one "sentence" of rows*T tokens with
@@ -395,6 +478,7 @@ struct RewardBufs {
   int32_t* Y; int32_t* tok_cur;
   float *feat_s, *feat_t, *p_rows, *p_base;
   float *win_vals, *win_pm; bool reuse;        // prefix-window reuse in the discriminator
+  BucketReuse bucket;                          // partial-window reuse (delta = 0: off)
   DiscBufs disc;
   int64_t act_rows, logits_rows, pr_rows;
   int disc_chunk;
@@ -459,6 +543,26 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
     const int64_t wrows = (int64_t)(p->B < b.disc_chunk ? p->B : b.disc_chunk) * p->T;
     b.win_vals = ar.get<float>(wrows * d->Fp);
     b.win_pm = ar.get<float>((int64_t)p->B * p->T * d->Fp);
+  }
+  b.bucket = BucketReuse{};
+  int max_w = 0, max_n = 0;
+  for (int i = 0; i < d->n_widths; ++i) {
+    max_w = d->widths[i] > max_w ? d->widths[i] : max_w;
+    max_n = d->n_filters[i] > max_n ? d->n_filters[i] : max_n;
+  }
+  const int dl = bucket_delta(p);
+  if (b.reuse && dl > 0 && (d->dim_word * es) % 128 == 0 && (max_w - 1) / dl < BUCKET_MAX_C && max_w > dl) {
+    b.bucket.delta = dl;
+    b.bucket.ye = ar.take((size_t)p->B * p->T * d->dim_word * es);
+    int64_t off = 0;
+    for (int i = 0; i < d->n_widths; ++i)
+      for (int c = 1; c * dl <= d->widths[i] - 1 && c < BUCKET_MAX_C; ++c) {
+        b.bucket.s_off[i][c] = off;
+        off += (int64_t)p->B * (p->T - d->widths[i] + 1) * d->n_filters[i];
+        off = (off + 63) / 64 * 64;
+      }
+    b.bucket.S = ar.get<float>(off > 0 ? off : 1);
+    b.bucket.raw = ar.get<float>((int64_t)REUSE_ROWS * dl * max_n);
   }
   return 0;
 }
@@ -555,6 +659,7 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
         NMTGAN_TRY(launch_prefix_max(b.win_vals, b.win_pm + (int64_t)r0 * T * d->Fp, rows, T, d->Fp, d->n_widths,
                                      d->widths, d->n_filters, ds));
       }
+      if (b.bucket.delta > 0) NMTGAN_TRY(bucket_tables(d, d->tgt, p->y, B, b.bucket, ds));
     }
     return 0;
   };
@@ -563,7 +668,8 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
     for (int r0 = lo; r0 < hi; r0 += b.disc_chunk) {
       const int rows = hi - r0 < b.disc_chunk ? hi - r0 : b.disc_chunk;
       PrefixReuse pr{b.win_pm, p->row_b + r0, p->row_g + r0, b.reuse ? p->row_g_host + r0 : nullptr};
-      NMTGAN_TRY(disc_features_chunk(d, d->tgt, b.Y + (int64_t)r0 * T, rows, b.feat_t, b.disc, ds, b.reuse ? &pr : nullptr));
+      NMTGAN_TRY(disc_features_chunk(d, d->tgt, b.Y + (int64_t)r0 * T, rows, b.feat_t, b.disc, ds, b.reuse ? &pr : nullptr,
+                                     b.reuse && b.bucket.delta > 0 ? &b.bucket : nullptr));
       NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s, p->row_b + r0, rows, d->Fp, d->head_w, d->head_b, b.p_rows + r0,
                                   nullptr, ds));
     }

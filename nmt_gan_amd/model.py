@@ -74,6 +74,7 @@ class Model(object):
         # two-stream schedule of get_reward (discriminator scoring of finished rollouts overlaps the decode steps)
         self.overlap = True
         self.group_slots = True        # 32 // rollnum prefix groups of a sentence per attention workgroup
+        self.conv_bucket_taps = 0      # partial-window reuse in the discriminator: 0 = library default, < 0 off
         self.aux_gemm_wgs = 0          # 0 = library default
         self.aux_min_rows = 0
         self._aux_stream = None
@@ -335,6 +336,7 @@ class Model(object):
         p.logits_chunk_rows = self.logits_chunk_rows
         p.disc_chunk_rows = self.disc_chunk_rows
         p.rewards = ptr(t["rewards"])
+        p.conv_bucket_taps = int(self.conv_bucket_taps)
         if "grp_table" in t:
             p.grp_table, p.grp_slots, p.grp_live = ptr(t["grp_table"]), int(plan.grp_slots), grp_live.ctypes.data
         if self.overlap:

@@ -91,8 +91,26 @@ def test_fullsize_schedules_agree(c2):
     finally:
         m.overlap = True
     assert np.array_equal(d1["rollouts"], c2["det"]["rollouts"])
-    assert np.array_equal(d1["p_rows"], c2["det"]["p_rows"])
-    assert np.array_equal(r1, c2["r"])
+    # the two schedules hand the discriminator different batches of rows; with the partial-window reuse the split
+    # of a straddling window into (prefix taps from y_sample) + (multiplied taps) follows the batch's smallest
+    # give_num, so its fp32 sum rounds differently, and a pooled feature that lands on the other side of a bf16
+    # rounding boundary (the highway GEMM's operand) moves the score of a sensitive row: mean |dP| 4e-6, 1 % of the
+    # rows above 1e-5, the worst 9e-3 - on rows where the bf16 tier is itself 0.05-0.15 from the fp64 oracle
+    dp = np.abs(d1["p_rows"] - c2["det"]["p_rows"])
+    assert dp.mean() < 5e-5 and dp.max() < 3e-2, (dp.mean(), dp.max())
+    assert np.abs(r1 - c2["r"]).max() < 3e-3
+    try:
+        m.overlap, m.conv_bucket_taps = False, -1          # every straddling window multiplied in full
+        r3 = m.get_reward(c2["x"], c2["xp"], c2["y"], c2["mask"], R, c2["disc"], max_len=T, bias_num=0.6,
+                          uniforms=c2["u"], return_details=True)
+        d3 = m.last_details
+    finally:
+        m.overlap, m.conv_bucket_taps = True, 0
+    assert np.array_equal(d3["rollouts"], c2["det"]["rollouts"])
+    dp = np.abs(d3["p_rows"] - c2["det"]["p_rows"])
+    print("partial-window reuse vs full windows: |dP| mean %.3g max %.3g" % (dp.mean(), dp.max()))
+    assert dp.mean() < 5e-5 and dp.max() < 3e-2, (dp.mean(), dp.max())
+    assert np.abs(r3 - c2["r"]).max() < 3e-3
     try:
         m.group_slots = False
         r2 = m.get_reward(c2["x"], c2["xp"], c2["y"], c2["mask"], R, c2["disc"], max_len=T, bias_num=0.6,

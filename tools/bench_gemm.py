@@ -27,6 +27,14 @@ SHAPES = [  # name, M, N, K, conv(P,T,E) or None, out_f32
     ("conv w37 S4096", 4096 * 14, 470, 37 * 512, (14, 50, 512), 1),
     ("conv w49 S4096", 4096 * 2, 590, 49 * 512, (2, 50, 512), 1),
     ("highway M4096 N4608 K4608", 4096, 4608, 4608, None, 1),
+    # bucket GEMMs of the partial-window experiment: 8 windows per rollout, first taps skipped, raw fp32 out
+    ("bucket w25 k17 S4096x8", 4096 * 8, 350, 17 * 512, (8, 50, 512), 2),
+    ("bucket w25 k9  S4096x8", 4096 * 8, 350, 9 * 512, (8, 50, 512), 2),
+    ("bucket w25 k1  S4096x8", 4096 * 8, 350, 1 * 512, (8, 50, 512), 2),
+    ("bucket w41 k33 S4096x8", 4096 * 8, 510, 33 * 512, (8, 50, 512), 2),
+    ("bucket w41 k17 S4096x8", 4096 * 8, 510, 17 * 512, (8, 50, 512), 2),
+    ("full   w25 S4096x26", 4096 * 26, 350, 25 * 512, (26, 50, 512), 1),
+    ("full   w41 S4096x10", 4096 * 10, 510, 41 * 512, (10, 50, 512), 1),
 ]
 
 
@@ -45,7 +53,14 @@ def run(name, M, N, K, conv, out_f32, iters=10):
     W = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).bfloat16()
     a.A, a.Wt, a.M, a.N, a.K = A.data_ptr(), W.data_ptr(), M, N, K
     keep = []
-    if conv:
+    if conv and out_f32 == 2:          # window rows, LINEAR epilogue, raw fp32 out
+        a.epilogue = L.EPI_LINEAR
+        bias = torch.zeros(N, device=dev)
+        out = torch.empty(M, N, device=dev, dtype=torch.float32)
+        a.bias, a.n_seg, a.seg_width = bias.data_ptr(), 1, N
+        a.out[0], a.ldo[0], a.out_f32[0], a.seg_scale[0] = out.data_ptr(), N, 1, 1.0
+        keep += [bias, out]
+    elif conv:
         a.epilogue = L.EPI_CONVMAX
         sc = torch.ones(N, device=dev); sh = torch.zeros(N, device=dev)
         pooled = torch.zeros(M // conv[0], 4608, device=dev)
