@@ -264,7 +264,7 @@ static void carve_disc(Arena& ar, const nmtgan_discriminator* d, int chunk, Disc
 // Windows a rollout shares with y_sample (those ending inside its given prefix) are not recomputed: their
 // max comes from pm[b*T + g][Fp] (prefix_max over one pass on y_sample); g_min = smallest give_num of the chunk.
 struct PrefixReuse { const float* pm; const int32_t* row_b; const int32_t* row_g; const int32_t* row_g_host; };
-static const int REUSE_ROWS = [] { const char* e = getenv("NMTGAN_REUSE_ROWS"); return e && atoi(e) > 0 ? atoi(e) : 4096; }();   // granularity at which the first computed window is chosen
+static const int REUSE_ROWS = [] { const char* e = getenv("NMTGAN_REUSE_ROWS"); return e && atoi(e) > 0 ? atoi(e) : 8192; }();   // granularity at which the first computed window is chosen
 
 // Windows that STRADDLE the give point (p < g < p + w) start with g - p tokens of y_sample.  Their taps are cut
 // into blocks of `delta`: a window whose first c*delta taps lie in the prefix takes that part of its sum from
