@@ -324,7 +324,8 @@ def main():
                                       "call: a conv call split into 256-column panels + remainder shows as two kernels "
                                       "in rocprof, 201 kernels per step for these 172 launches, same total); traffic = HBM "
                                       "bytes per launch from the committed PMC summary "
-                                      "profiles/r1_c2_bf16_hbm_traffic.json"}
+                                      "profiles/r1_c2_bf16_hbm_traffic.json (for gemm_conv: the fused conv+max "
+                                      "kernels only; the partial-window GEMMs share their kernel with the decoder's)"}
         result["roofline_all"] = rows
         result["profiled_step_ms"] = round(profiled_ms, 2)
 

@@ -1,3 +1,6 @@
+"""Diagnostic for the discriminator's partial-window reuse at C2 size (run on a GPU box: python tools/check_conv_reuse.py
+[bf16|fp32]): P(real) of every rollout with the reuse on/off on both schedules, the rows that differ most checked
+against the fp64 CPU oracle, and the tier's accuracy on 48 random rows.  Test infrastructure (imports oracle/)."""
 import sys, numpy as np, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import nmt_gan_amd as N
