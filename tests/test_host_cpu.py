@@ -35,6 +35,32 @@ def test_ctypes_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.GemmArgs) % 8 == 0 and C.sizeof(_lib.RewardPlan) % 8 == 0
 
 
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """Every hand-mirrored ctypes struct has the size the C compiler gives the struct of include/nmtgan.h,
+    and its last field sits at the same offset (gcc on the header itself)."""
+    from nmt_gan_amd import _lib
+    pairs = {"nmtgan_gemm_args": (_lib.GemmArgs, "ldw"), "nmtgan_embed_args": (_lib.EmbedArgs, "op_dtype"),
+             "nmtgan_addln_args": (_lib.AddLnArgs, "zero_row"), "nmtgan_attn_args": (_lib.AttnArgs, "q_op_dtype"),
+             "nmtgan_attn_group_args": (_lib.AttnGroupArgs, "n_entries"), "nmtgan_sample_args": (_lib.SampleArgs, "out"),
+             "nmtgan_generator": (_lib.Generator, "dec"), "nmtgan_discriminator": (_lib.Discriminator, "head_b"),
+             "nmtgan_reward_plan": (_lib.RewardPlan, "conv_bucket_taps")}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "nmtgan.h"', 'int main(void) {']
+    for cname, (_, last) in pairs.items():
+        src.append('  printf("%s %%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (cname, cname, cname, last))
+    src += ['  return 0;', '}']
+    cfile = tmp_path / "abi.c"
+    cfile.write_text("\n".join(src))
+    exe = tmp_path / "abi"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-I", inc, str(cfile), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    for line in out.strip().splitlines():
+        cname, size, off = line.split()
+        cls, last = pairs[cname]
+        assert C.sizeof(cls) == int(size), (cname, C.sizeof(cls), size)
+        assert getattr(cls, last).offset == int(off), (cname, last)
+
+
 def test_entry_points_validate_before_launch():
     """Host-side argument checks fail with a message and never touch the GPU."""
     from nmt_gan_amd import _lib
