@@ -71,8 +71,17 @@ class DisCNN(object):
         self._keep = []            # device tensors kept alive for the C struct
         self._c = None
         self._ws = None
+        self.reload = bool(reload)
+        if self.reload:                # cnn_discriminator.py:209-217: saver.restore(sess, saveto) in the constructor
+            self.restore(saveto)
 
     # ------------------------------------------------------------------ weights
+    def restore(self, prefix=None):
+        """tf.train.Saver(params in scope).restore (cnn_discriminator.py:202-217): every variable of the
+        scope, BatchNorm moving statistics included, from the TF V2 checkpoint prefix (default `saveto`)."""
+        from . import tf_checkpoint
+        return self.load_weights(tf_checkpoint.LazyCheckpoint(str(self.saveto if prefix is None else prefix)))
+
     def load_weights(self, W: Dict[str, np.ndarray]):
         """Pack TF-named variables (discnn/model_self/..., discnn/conv_maxpool-w/...)
         for the kernels: conv filters as Wt[n_w][w*E], conv bias + inference BN folded into

@@ -98,13 +98,22 @@ class Model(object):
         self.max_len = int(max_len)
 
     def init_and_restore(self, modelFile=None, weights: Optional[Dict[str, np.ndarray]] = None):
-        """Reference: model.py:425-435 (tf.train.Saver restore).  Accepts a dict of TF-named arrays
-         or a .npz written with those names."""
+        """Reference: model.py:425-435 (tf.train.Saver restore of the trainable variables from `modelFile`,
+        or from the latest checkpoint of config.train.logdir when it is None).  `modelFile` is a TF V2
+        checkpoint prefix (read by nmt_gan_amd.tf_checkpoint, no TensorFlow) or a .npz with the same
+        variable names; `weights=` takes the dict directly."""
         if weights is None:
+            from . import tf_checkpoint
             if modelFile is None:
-                raise ValueError("init_and_restore: pass weights= or a .npz modelFile")
-            with np.load(modelFile, allow_pickle=False) as z:
-                weights = {k: z[k] for k in z.files}
+                logdir = _cfg_get(self.config, "train.logdir")
+                modelFile = tf_checkpoint.latest_checkpoint(logdir) if logdir else None
+                if modelFile is None:
+                    raise ValueError("init_and_restore: no modelFile and no checkpoint under config.train.logdir")
+            if str(modelFile).endswith(".npz"):
+                with np.load(modelFile, allow_pickle=False) as z:
+                    weights = {k: z[k] for k in z.files}
+            else:
+                weights = tf_checkpoint.LazyCheckpoint(str(modelFile))
         self.load_weights(weights)
 
     def load_weights(self, W: Dict[str, np.ndarray]):

@@ -68,3 +68,41 @@ def test_same_uniforms_same_rewards_any_chunking(cuda):
         parts.append(m._reward_local(g["x"][b0:b1], g["xp"][b0:b1], g["y"][b0:b1], g["mask"][b0:b1], R, disc, T, 0.6,
                                      u, b_offset=b0, B_global=B, return_details=False).cpu().numpy())
     assert np.abs(np.concatenate(parts) - a).max() < 1e-4
+
+
+def test_restore_from_tf_checkpoints_reproduces_goldens(cuda, tmp_path):
+    """Row f-2: weights arrive through TF V2 bundles (Model.init_and_restore(modelFile) / latest checkpoint of
+    config.train.logdir, DisCNN(reload=True, saveto=...)) instead of dicts; the bundle also carries variables
+    the path does not use (optimizer slots), which the restore must skip."""
+    import nmt_gan_amd as N
+    from helpers import Cfg, facade_config
+    from nmt_gan_amd import tf_checkpoint as ck
+    with np.load(GOLD, allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    T, R = int(g["T"]), int(g["R"])
+    gcfg, dcfg = tiny_cfgs(T=T)
+    Wg, Wd = O.init_generator_weights(gcfg, int(g["gen_seed"])), disc_weights(dcfg, int(g["disc_seed"]))
+    extra = {"global_step": np.int64(7), "embedding/softmax/kernel/RMSProp": np.ones((3, 3), np.float32)}
+    gdir = tmp_path / "gen_logdir"
+    ck.save_checkpoint(str(gdir / "model_epoch_0_step_7"), dict(Wg, **extra))
+    ck.save_checkpoint(str(tmp_path / "disc" / "discriminator"), dict(Wd, **{"discnn/global_step": np.int64(3)}))
+    cfg = facade_config(gcfg)
+    cfg["train"] = Cfg(shared_embedding=gcfg.shared_embedding, logdir=str(gdir))
+    rewards = []
+    for model_file in (str(gdir / "model_epoch_0_step_7"), None):       # explicit prefix, then latest_checkpoint(logdir)
+        m = N.Model(cfg, precision="fp32")
+        m.build_train_model()
+        m.build_generate(T)
+        m.build_rollout_generate(T)
+        m.init_and_restore(modelFile=model_file)
+        disc = N.DisCNN(None, T, 2, dcfg.vocab_size, 8, dcfg.dim_word, dcfg.filter_sizes, dcfg.num_filters,
+                        vocab_size_s=dcfg.vocab_size_s, precision="fp32", reload=True,
+                        saveto=str(tmp_path / "disc" / "discriminator"))
+        rewards.append(m.get_reward(g["x"], g["xp"], g["y"], g["mask"], R, disc, max_len=T, bias_num=0.6,
+                                    uniforms=g["u"]))
+        assert np.array_equal(m.generate_step(g["x"]), g["greedy"])
+    assert np.abs(rewards[0] - g["rewards_bias06"]).max() < 1e-5
+    assert np.array_equal(rewards[0], rewards[1])
+    with pytest.raises(Exception):
+        N.DisCNN(None, T, 2, dcfg.vocab_size, 8, dcfg.dim_word, dcfg.filter_sizes, dcfg.num_filters,
+                 vocab_size_s=dcfg.vocab_size_s, reload=True, saveto=str(tmp_path / "missing"))
