@@ -349,6 +349,31 @@ int nmtgan_teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, co
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Policy-gradient step of the generator: what gan_train.py:112 runs right after
+ * get_reward.  Replaces sess.run([generate_g_loss, generate_g_grad, generate_g_optm]) of
+ * Model.generate_step_and_update (model.py:273-276): decoder(shift_right(Y)) (model.py:178-184) ->
+ * gan_output (model.py:649-666)  loss = -sum_{b,t} softmax(logits)[b,t,Y[b,t]] * reward[b,t] / B
+ * -> compute_gradients over every trainable variable -> RMSProp (model.py:119).
+ * nmtgan_pg_grads: forward + loss + backward.  `grads` mirrors the nmtgan_generator it differentiates: every
+ *   pointer names a WRITABLE fp32 buffer with the layout of the weight it belongs to (matrices Wt[N][K],
+ *   vectors [N], tables emb_src/emb_dst/softmax_w [V][d]; op_dtype/timing/sizes of `grads` are ignored) and
+ *   is overwritten.  loss: 1 float on the device; p_target (optional): [B][T] probability of Y[b,t].
+ *   x [B][Ls], x_pad [B][Ls] (1 where x == 0), y [B][T], dec_in = shift_right(y), reward [B][T].
+ *   Residual dropout is neutralised as on the rollout path; shared_embedding models are rejected;
+ *   Ls, T <= 90 (the attention backward holds two score matrices in LDS).
+ * nmtgan_rmsprop_update: dense ApplyRMSProp over n contiguous parameters (ms += (g*g - ms)(1 - decay);
+ *   mom = mom*momentum + lr*g/sqrt(ms + eps); w -= mom) with g = grad * grad_scale (the tower average of
+ *   model.py:689-722); mom may be NULL (momentum 0); w_op (optional) receives the updated parameters in
+ *   op_dtype (the MFMA operand copy of a bf16 model).
+ */
+size_t nmtgan_pg_workspace_bytes(const nmtgan_generator* g, int B, int Ls, int T);
+int nmtgan_pg_grads(const nmtgan_generator* g, const nmtgan_generator* grads, const int32_t* x, const uint8_t* x_pad,
+                    const int32_t* y, const int32_t* dec_in, const float* reward, int B, int Ls, int T, float* loss,
+                    float* p_target, void* workspace, size_t workspace_bytes, void* stream);
+int nmtgan_rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay,
+                          float momentum, float eps, float grad_scale, void* w_op, int op_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement hook (no counterpart in the reference; used by bench.py's roofline leg only).
  * Between start and stop every kernel launch is bracketed by HIP events on its own stream;
  * stop synchronises the device and returns summed milliseconds and launch counts per class:

@@ -128,6 +128,10 @@ EXPORTS = {
     "nmtgan_generate_greedy": (i32, [C.POINTER(Generator), vp, vp, i32, i32, i32, vp, vp, sz, vp]),
     "nmtgan_teacher_forced_workspace_bytes": (sz, [C.POINTER(Generator), i32, i32, i32]),
     "nmtgan_teacher_forced_logits": (i32, [C.POINTER(Generator), vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]),
+    "nmtgan_pg_workspace_bytes": (sz, [C.POINTER(Generator), i32, i32, i32]),
+    "nmtgan_pg_grads": (i32, [C.POINTER(Generator), C.POINTER(Generator), vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
+                              sz, vp]),
+    "nmtgan_rmsprop_update": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]),
     "nmtgan_profile_classes": (i32, []),
     "nmtgan_profile_start": (i32, []),
     "nmtgan_profile_stop": (i32, [C.POINTER(f64), C.POINTER(i64), i32]),

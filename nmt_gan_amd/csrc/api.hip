@@ -43,6 +43,12 @@ int teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, const uin
 int generate_workspace(const nmtgan_generator* g, int B, int Ls, int T, size_t* bytes);
 int generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_pad, int B, int Ls, int T,
                     int32_t* y, void* ws, size_t ws_bytes, hipStream_t st);
+int pg_workspace(const nmtgan_generator* g, int B, int Ls, int T, size_t* bytes);
+int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_t* x, const uint8_t* x_pad, const int32_t* y,
+             const int32_t* dec_in, const float* reward, int B, int Ls, int T, float* loss, float* p_target, void* ws,
+             size_t ws_bytes, hipStream_t st);
+int rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay, float momentum,
+                   float eps, float grad_scale, void* w_op, int op_dtype, hipStream_t st);
 }  // namespace nmtgan
 
 using namespace nmtgan;
@@ -149,6 +155,22 @@ int nmtgan_teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, co
                                  size_t workspace_bytes, void* stream) {
   return teacher_forced_logits(g, x, x_pad, dec_in, B, Ls, T, logits, workspace, workspace_bytes,
                                (hipStream_t)stream);
+}
+
+size_t nmtgan_pg_workspace_bytes(const nmtgan_generator* g, int B, int Ls, int T) {
+  size_t b = 0;
+  if (!g) { set_error("pg_workspace: null generator"); return 0; }
+  return pg_workspace(g, B, Ls, T, &b) == 0 ? b : 0;
+}
+int nmtgan_pg_grads(const nmtgan_generator* g, const nmtgan_generator* grads, const int32_t* x, const uint8_t* x_pad,
+                    const int32_t* y, const int32_t* dec_in, const float* reward, int B, int Ls, int T, float* loss,
+                    float* p_target, void* workspace, size_t workspace_bytes, void* stream) {
+  return pg_grads(g, grads, x, x_pad, y, dec_in, reward, B, Ls, T, loss, p_target, workspace, workspace_bytes,
+                  (hipStream_t)stream);
+}
+int nmtgan_rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay,
+                          float momentum, float eps, float grad_scale, void* w_op, int op_dtype, void* stream) {
+  return rmsprop_update(w, ms, mom, grad, n, lr, decay, momentum, eps, grad_scale, w_op, op_dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

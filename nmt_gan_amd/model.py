@@ -79,6 +79,8 @@ class Model(object):
         self.aux_min_rows = 0
         self._aux_stream = None
         self.last_details = None
+        self.g_optimizer = 'rmsprop'
+        self._W_src, self._train = None, None
 
     # ------------------------------------------------------------------ graph-building surface
     def build_train_model(self):
@@ -90,8 +92,11 @@ class Model(object):
             self._logger.warning("residual_dropout_rate=%g ignored on the rollout path (deterministic rollouts)", rate)
 
     def build_generate(self, max_len, generate_devices=None, optimizer='rmsprop'):
-        """Reference: model.py:108-201.  Only the greedy sampler half is in scope."""
+        """Reference: model.py:108-201: the greedy sampler (generate_step) and the policy-gradient update
+        (generate_step_and_update).  As in the reference only 'adadelta' selects anything but RMSProp: its
+        `if adam / if adadelta / else rmsprop` chain (model.py:111-119) overwrites the Adam choice."""
         self.max_len = int(max_len)
+        self.g_optimizer = 'adadelta' if optimizer == 'adadelta' else 'rmsprop'
 
     def build_rollout_generate(self, max_len, roll_generate_devices=None):
         """Reference: model.py:203-266."""
@@ -175,6 +180,7 @@ class Model(object):
             lnorm(b.ln1, p + "layer_norm_1")
             lnorm(b.ln2, p + "layer_norm_2")
         self._keep, self._c = keep, c
+        self._W_src, self._train = W, None
         return self
 
     @property
@@ -221,8 +227,177 @@ class Model(object):
                 for y_str in data_util.indices_to_words_del_pad(dealed, 'dst'):
                     out.write(y_str + '\n')
 
-    def generate_step_and_update(self, sentence_x, sentence_y, reward):
-        raise NotImplementedError("policy-gradient update is outside the rollout-reward path (SURVEY section 8f-3)")
+    # ------------------------------------------------------------------ policy-gradient update (row f-3)
+    def _param_specs(self):
+        """(TF variable name, kind, path into the nmtgan_generator struct) of every trainable variable
+        (SURVEY Appendix C).  kind: mat = dense kernel packed Wt[N][K] and read in op dtype, vec = fp32 vector,
+        tab = fp32 embedding table, smx = softmax table [V][d] read in op dtype."""
+        specs = [("embedding/src_embedding/kernel", "tab", ("emb_src",)),
+                 ("embedding/dst_embedding/kernel", "tab", ("emb_dst",)),
+                 ("embedding/softmax/kernel", "smx", ("softmax_w",))]
+
+        def dense(name, path):
+            specs.append((name + "/kernel", "mat", path + ("w",)))
+            specs.append((name + "/bias", "vec", path + ("b",)))
+
+        def lnorm(name, path):
+            specs.append((name + "/layer_norm_scale", "vec", path + ("g",)))
+            specs.append((name + "/layer_norm_bias", "vec", path + ("b",)))
+
+        for i in range(self.num_blocks):
+            p, e = "encoder/block_%d/" % i, ("enc", i)
+            dense(p + "encoder_self_attention/qkv_transform_single", e + ("qkv",))
+            dense(p + "encoder_self_attention/output_transform_single", e + ("o",))
+            dense(p + "conv_hidden_relu/conv1_single", e + ("ffn1",))
+            dense(p + "conv_hidden_relu/conv2_single", e + ("ffn2",))
+            lnorm(p + "layer_norm", e + ("ln0",))
+            lnorm(p + "layer_norm_1", e + ("ln1",))
+            p, b = "decoder/block_%d/" % i, ("dec", i)
+            dense(p + "decoder_self_attention/qkv_transform_single", b + ("qkv",))
+            dense(p + "decoder_self_attention/output_transform_single", b + ("o",))
+            dense(p + "decoder_vanilla_attention/q_transform_single", b + ("cq",))
+            dense(p + "decoder_vanilla_attention/kv_transform_single", b + ("ckv",))
+            dense(p + "decoder_vanilla_attention/output_transform_single", b + ("co",))
+            dense(p + "conv_hidden_relu/conv1_single", b + ("ffn1",))
+            dense(p + "conv_hidden_relu/conv2_single", b + ("ffn2",))
+            lnorm(p + "layer_norm", b + ("ln0",))
+            lnorm(p + "layer_norm_1", b + ("ln1",))
+            lnorm(p + "layer_norm_2", b + ("ln2",))
+        return specs
+
+    def _enable_training(self):
+        """Re-homes the weights for the update step: ONE flat fp32 master buffer (every tensor in its packed
+        layout at a 256-byte aligned offset), one flat gradient buffer and one flat RMSProp accumulator with the
+        same offsets - so the optimizer is one launch and the multi-GPU gradient average one RCCL all-reduce -
+        plus, for a bf16 model, a flat bf16 operand copy the optimizer refreshes.  The nmtgan_generator struct is
+        re-pointed into these buffers; a second struct with the same shape names the gradients."""
+        if self._train is not None:
+            return self._train
+        if self.shared_embedding:
+            raise NotImplementedError("generate_step_and_update: shared_embedding models are not supported")
+        W = self._W_src
+        if W is None:
+            raise RuntimeError("Model: init_and_restore()/load_weights() has not been called")
+        dev = self.device
+        specs, chunks, shapes, off = self._param_specs(), [], {}, 0
+        for name, kind, path in specs:
+            a = np.asarray(W[name], np.float32)
+            shapes[name] = a.shape
+            if kind == "mat":
+                a = a.reshape(a.shape[-2], a.shape[-1]).T            # Wt[N][K]
+            a = np.ascontiguousarray(a).reshape(-1)
+            chunks.append((name, kind, path, off, a))
+            off += (a.size + 63) // 64 * 64
+        host = np.zeros(off, np.float32)
+        for _, _, _, o, a in chunks:
+            host[o:o + a.size] = a
+        master = torch.from_numpy(host).to(dev)
+        grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        ms = torch.ones(off, dtype=torch.float32, device=dev)        # RMSProp `rms` slot starts at one
+        opc = master.to(torch.bfloat16) if self.precision == "bf16" else None
+        c, gc = _lib.Generator(), _lib.Generator()
+        old = self._c
+        for f in ("op_dtype", "d", "heads", "n_blocks", "vocab_src", "vocab_dst", "emb_mult", "timing", "max_pos"):
+            setattr(c, f, getattr(old, f))
+            setattr(gc, f, getattr(old, f))
+
+        def put(struct, path, addr):
+            obj = struct
+            for k in path[:-1]:
+                obj = obj[k] if isinstance(k, int) else getattr(obj, k)
+            setattr(obj, path[-1], addr)
+
+        index = {}
+        for name, kind, path, o, a in chunks:
+            use_op = opc is not None and kind in ("mat", "smx")
+            put(c, path, (opc.data_ptr() + 2 * o) if use_op else (master.data_ptr() + 4 * o))
+            put(gc, path, grad.data_ptr() + 4 * o)
+            index[name] = (kind, o, a.size)
+        timing = [t for t in self._keep if t.data_ptr() == old.timing]
+        self._keep = timing + [master, grad, ms] + ([opc] if opc is not None else [])
+        self._c = c
+        self._train = dict(master=master, grad=grad, ms=ms, op=opc, gc=gc, index=index, shapes=shapes, n=off,
+                           loss=torch.zeros(1, dtype=torch.float32, device=dev), steps=0)
+        return self._train
+
+    def get_weights(self) -> Dict[str, np.ndarray]:
+        """Current trainable variables under their TF names and shapes (what tf.train.Saver would write)."""
+        if self._train is None:
+            return {name: np.asarray(self._W_src[name], np.float32) for name, _, _ in self._param_specs()}
+        tr = self._train
+        host = tr["master"].cpu().numpy()
+        out = {}
+        for name, (kind, o, n) in tr["index"].items():
+            a = host[o:o + n]
+            shp = tr["shapes"][name]
+            if kind == "mat":
+                a = a.reshape(shp[-1], shp[-2]).T
+            out[name] = np.ascontiguousarray(a.reshape(shp))
+        return out
+
+    def save(self, prefix):
+        """saver.save(sess, prefix) (gan_train.py:118): a TF V2 bundle of the trainable variables."""
+        from . import tf_checkpoint
+        tf_checkpoint.save_checkpoint(str(prefix), self.get_weights())
+
+    def generate_step_and_update(self, sentence_x, sentence_y, reward, *, return_grads=False):
+        """Reference: model.py:273-276 -> the loss half of build_generate (model.py:178-190): teacher-forced
+        decoder over shift_right(Y), gan_output loss -sum p(y_t) reward_t / B (model.py:649-666), gradients of
+        every trainable variable, RMSProp(config.generator.learning_rate) update.  Returns the loss.
+        With torch.distributed initialised the sentences are split across ranks like the reference's towers
+        (split_tensor), every rank's loss is normalised by its own batch and gradients are averaged
+        (average_gradients, model.py:689-722) with one RCCL all-reduce of the flat gradient buffer."""
+        if self.g_optimizer != 'rmsprop':
+            raise NotImplementedError("generate_step_and_update: only the RMSProp optimizer is built (adadelta is not)")
+        x = np.ascontiguousarray(np.asarray(sentence_x), dtype=np.int32)
+        y = np.ascontiguousarray(np.asarray(sentence_y), dtype=np.int32)
+        r = np.ascontiguousarray(np.asarray(reward), dtype=np.float32)
+        if x.ndim != 2 or y.ndim != 2 or x.shape[0] != y.shape[0] or r.shape != y.shape:
+            raise ValueError("generate_step_and_update: x [B, Ls], y [B, T] and reward [B, T] expected")
+        world, rank = 1, 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+        bounds = split_bounds(x.shape[0], world)
+        b0, b1 = bounds[rank], bounds[rank + 1]
+        if b1 <= b0:
+            raise ValueError("generate_step_and_update: batch smaller than the number of ranks")
+        x, y, r = x[b0:b1], y[b0:b1], r[b0:b1]
+        B, Ls = x.shape
+        T = y.shape[1]
+        tr = self._enable_training()
+        g = self.c_struct
+        xd = self._dev_i32(x)
+        pad = (xd == 0).to(torch.uint8).contiguous()
+        yd, dec_in = self._dev_i32(y), self._dev_i32(shift_right(y))
+        rd = torch.as_tensor(r).to(self.device)
+        ws = self._workspace(lib.nmtgan_pg_workspace_bytes(C.byref(g), B, Ls, T))
+        st = _lib.stream_ptr()
+        check(lib.nmtgan_pg_grads(C.byref(g), C.byref(tr["gc"]), ptr(xd), ptr(pad), ptr(yd), ptr(dec_in), ptr(rd), B, Ls, T,
+                                  ptr(tr["loss"]), None, ptr(ws), ws.numel(), st), "nmtgan_pg_grads")
+        loss = tr["loss"].clone()
+        if world > 1:
+            work_g, work_l = tr["grad"], loss
+            if torch.distributed.get_backend() != "nccl":
+                work_g, work_l = tr["grad"].cpu(), loss.cpu()
+            torch.distributed.all_reduce(work_g)
+            torch.distributed.all_reduce(work_l)
+            if work_g is not tr["grad"]:
+                tr["grad"].copy_(work_g)
+            loss = work_l.to(self.device) / world                     # tf.reduce_mean(loss_list), model.py:187
+        grads = None
+        if return_grads:
+            host = (tr["grad"] / world).cpu().numpy()
+            grads = {}
+            for name, (kind, o, n) in tr["index"].items():
+                a, shp = host[o:o + n], tr["shapes"][name]
+                grads[name] = np.ascontiguousarray((a.reshape(shp[-1], shp[-2]).T if kind == "mat" else a).reshape(shp))
+        lr = float(_cfg_get(self.config, "generator.learning_rate", 1e-5))
+        check(lib.nmtgan_rmsprop_update(ptr(tr["master"]), ptr(tr["ms"]), None, ptr(tr["grad"]), tr["n"], lr, 0.9, 0.0,
+                                        1e-10, 1.0 / world, ptr(tr["op"]), self._op, st), "nmtgan_rmsprop_update")
+        tr["steps"] += 1
+        torch.cuda.synchronize(self.device)
+        out = float(loss.item())
+        return (out, grads) if return_grads else out
 
     # ------------------------------------------------------------------ parity hook
     def teacher_forced_logits(self, x, y):

@@ -456,6 +456,46 @@ def generate_step(W, cfg, x, max_len: int) -> np.ndarray:
     return cur.numpy().astype(np.int32)
 
 
+# --------------------------------------------------------------------------- policy-gradient step
+def pg_loss(W, cfg: GenConfig, x, y, reward) -> torch.Tensor:
+    """model.py:649-666 gan_output on decoder(shift_right(Y)) (model.py:178-184):
+    g_loss = -sum_{b,t} softmax(logits)[b, t, Y[b,t]] * reward[b,t] / B   (probabilities, not log-probs)."""
+    dt = W[_emb_name(cfg, "softmax")].dtype
+    xt = torch.as_tensor(np.asarray(x), dtype=torch.int64)
+    yt = torch.as_tensor(np.asarray(y), dtype=torch.int64)
+    enc = encoder(W, cfg, xt)
+    logits = top(W, cfg, decoder(W, cfg, shift_right(yt), enc))
+    p_y = torch.softmax(logits, -1).gather(-1, yt[..., None])[..., 0]
+    return -(p_y * torch.as_tensor(np.asarray(reward)).to(dt)).sum() / xt.shape[0]
+
+
+def pg_loss_and_grads(Wnp: Dict[str, np.ndarray], cfg: GenConfig, x, y, reward, dtype=torch.float64):
+    """optimizer.compute_gradients(g_loss) over every trainable variable (model.py:181): autograd through
+    this file's encoder/decoder/top.  Returns (loss, {name: grad ndarray in the variable's shape})."""
+    W = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype).requires_grad_(True) for k, v in Wnp.items()}
+    loss = pg_loss(W, cfg, x, y, reward)
+    loss.backward()
+    return float(loss.item()), {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().numpy()
+                                for k, v in W.items()}
+
+
+def rmsprop_apply(W: Dict[str, np.ndarray], G: Dict[str, np.ndarray], ms: Dict[str, np.ndarray], lr: float,
+                  decay: float = 0.9, momentum: float = 0.0, epsilon: float = 1e-10, mom=None):
+    """tf.train.RMSPropOptimizer(learning_rate) defaults (model.py:119; decay 0.9, momentum 0, epsilon 1e-10,
+    `rms` slot initialised to ones), dense ApplyRMSProp as recalled from TF 1.x (unverifiable offline):
+    ms += (g*g - ms) * (1 - decay);  mom = mom * momentum + lr * g / sqrt(ms + epsilon);  var -= mom.
+    average_gradients (model.py:689-722) densifies the embedding gradients (tf.expand_dims on IndexedSlices), so
+    every row of every table takes the dense update.  In place on W and ms (and mom when given)."""
+    for k in W:
+        g = np.asarray(G[k], W[k].dtype)
+        ms[k] += (g * g - ms[k]) * (1.0 - decay)
+        step = lr * g / np.sqrt(ms[k] + epsilon)
+        if mom is not None:
+            mom[k][...] = mom[k] * momentum + step
+            step = mom[k]
+        W[k] -= step.astype(W[k].dtype)
+
+
 # --------------------------------------------------------------------------- discriminator
 def _conv_bn_relu_max(e, Wd, scope):
     """cnn_layer.conv_op + max_pool (cnn_discriminator.py:88-109, 22-33, 469).  e: [B,T,E]."""

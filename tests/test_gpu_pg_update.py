@@ -1,0 +1,132 @@
+"""Policy-gradient update of the generator (reference Model.generate_step_and_update,
+model.py:273-276, 178-190, 649-666) through the C ABI against the oracle's autograd (fp64) + RMSProp
+restatement.  Parity unpinned like the rest of the path (no TensorFlow here): the oracle is this repo's
+restatement; tolerances are written in each test."""
+import numpy as np
+import pytest
+
+from helpers import Cfg, disc_weights, facade_config, make_gpu_pair, rel_err, tiny_cfgs
+from oracle import nmtgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(T=12, B=5, seed=11, reward_scale=1.0):
+    gcfg, dcfg = tiny_cfgs(T=T)
+    Wg = O.init_generator_weights(gcfg, 0)
+    x, y = O.synthetic_batch(B, T, gcfg.src_vocab_size, gcfg.dst_vocab_size, seed=seed, eos_rows=(1, 3), short_src_rows=(2,))
+    yd, mask = O.deal_generated_samples(y)
+    rng = np.random.default_rng(seed)
+    reward = ((rng.random((B, T)).astype(np.float32) - np.float32(0.6)) * mask * np.float32(reward_scale)).astype(np.float32)
+    return gcfg, dcfg, Wg, x, yd, mask, reward
+
+
+def _model(gcfg, Wg, precision, T, lr=1e-5):
+    import nmt_gan_amd as N
+    cfg = facade_config(gcfg)
+    cfg["generator"] = Cfg(learning_rate=lr)
+    m = N.Model(cfg, precision=precision)
+    m.build_train_model()
+    m.build_generate(T, optimizer='rmsprop')
+    m.build_rollout_generate(T)
+    m.init_and_restore(weights=Wg)
+    return m
+
+
+def test_fp32_loss_and_gradients_match_autograd(cuda):
+    """fp32 tier: loss within 1e-5 relative, every gradient tensor within 1e-4 at tensor scale
+    (||dgpu - dref||_inf / ||dref||_inf) of the fp64 autograd gradient."""
+    gcfg, _, Wg, x, y, mask, reward = _case()
+    ref_loss, ref_g = O.pg_loss_and_grads(Wg, gcfg, x, y, reward)
+    m = _model(gcfg, Wg, "fp32", y.shape[1])
+    loss, grads = m.generate_step_and_update(x, y, reward, return_grads=True)
+    assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss)
+    assert set(grads) == set(ref_g)
+    worst = max((rel_err(grads[k], ref_g[k]), k) for k in ref_g if np.abs(ref_g[k]).max() > 0)
+    assert worst[0] < 1e-4, worst
+    for k in ref_g:                                     # variables the loss cannot reach stay at exactly zero
+        if np.abs(ref_g[k]).max() == 0:
+            assert np.abs(grads[k]).max() == 0, k
+    # rows of the embedding tables no token touched have zero gradient (dense gradient of tf.gather)
+    used = np.unique(x)
+    untouched = np.setdiff1d(np.arange(gcfg.src_vocab_size), used)
+    assert np.abs(grads["embedding/src_embedding/kernel"][untouched]).max() == 0
+
+
+def test_fp32_two_updates_match_oracle_rmsprop(cuda):
+    """Two RMSProp steps (lr raised so the step is far above fp32 rounding of the weights): the weight change
+    of every tensor within 2e-3 (tensor scale) of the oracle's plus the fp32 rounding of the stored weight, the
+    second loss within 1e-4 relative."""
+    lr = 1e-2
+    gcfg, _, Wg, x, y, mask, reward = _case(reward_scale=50.0)
+    W = {k: np.array(v, np.float64) for k, v in Wg.items()}
+    ms = {k: np.ones_like(v) for k, v in W.items()}
+    ref_losses = []
+    for _ in range(2):
+        l, G = O.pg_loss_and_grads(W, gcfg, x, y, reward)
+        ref_losses.append(l)
+        O.rmsprop_apply(W, G, ms, lr)
+    m = _model(gcfg, Wg, "fp32", y.shape[1], lr=lr)
+    losses = [m.generate_step_and_update(x, y, reward) for _ in range(2)]
+    assert abs(losses[0] - ref_losses[0]) <= 1e-5 * abs(ref_losses[0])
+    assert abs(losses[1] - ref_losses[1]) <= 1e-4 * abs(ref_losses[1])
+    assert abs(ref_losses[1] - ref_losses[0]) > 1e-3 * abs(ref_losses[0])      # the step is visible
+    got = m.get_weights()
+    for k in W:
+        d_ref = W[k] - np.asarray(Wg[k], np.float64)
+        d_got = got[k].astype(np.float64) - np.asarray(Wg[k], np.float64)
+        assert got[k].shape == np.asarray(Wg[k]).shape
+        # two fp32 roundings of the stored weight (one per step) ride on top of the 2e-3 of the step itself
+        tol = 2e-3 * np.abs(d_ref).max() + 2 * np.finfo(np.float32).eps * np.abs(Wg[k]).max()
+        assert np.abs(d_got - d_ref).max() <= tol, (k, np.abs(d_got - d_ref).max(), tol)
+
+
+def test_bf16_gradients_close_to_autograd(cuda):
+    """bf16 operands (fp32 accumulation, fp32 gradients): loss within 2e-2 relative; gradients within 8e-2 at
+    tensor scale and cosine similarity > 0.995 per tensor - operand rounding (2^-9) compounds over 18 sub-layers
+    forward and backward."""
+    gcfg, _, Wg, x, y, mask, reward = _case()
+    ref_loss, ref_g = O.pg_loss_and_grads(Wg, gcfg, x, y, reward)
+    m = _model(gcfg, Wg, "bf16", y.shape[1])
+    loss, grads = m.generate_step_and_update(x, y, reward, return_grads=True)
+    assert abs(loss - ref_loss) <= 2e-2 * abs(ref_loss)
+    for k in ref_g:
+        a, b = grads[k].astype(np.float64).ravel(), ref_g[k].ravel()
+        if np.abs(b).max() == 0:
+            continue
+        assert rel_err(a, b) < 8e-2, (k, rel_err(a, b))
+        assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.995, k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_updated_weights_drive_the_rollout_path_and_survive_a_checkpoint(cuda, tmp_path, precision):
+    """gan_train.py:102-118 in sequence: get_reward -> generate_step_and_update -> saver.save, then the next
+    iteration's get_reward runs on the UPDATED weights: identical to a fresh model restored from the bundle."""
+    T, R = 10, 2
+    gcfg, dcfg, Wg, x, y, mask, _ = _case(T=T, B=3)
+    Wd = disc_weights(dcfg, 1)
+    m, disc = make_gpu_pair(gcfg, dcfg, Wg, Wd, precision, T)
+    m.config["generator"] = Cfg(learning_rate=1e-2)
+    xp = O.extend_sentence_to_maxlen(x, T)
+    u = np.random.default_rng(5).random((R, T - 1, 3, T), dtype=np.float32)
+    r0 = m.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u)
+    loss = m.generate_step_and_update(x, y, r0 * np.float32(50.0))
+    assert np.isfinite(loss)
+    r1 = m.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u)
+    m.save(str(tmp_path / "gen" / "model_step_1"))
+    m2, _ = make_gpu_pair(gcfg, dcfg, Wg, Wd, precision, T)
+    m2.init_and_restore(modelFile=str(tmp_path / "gen" / "model_step_1"))
+    r2 = m2.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u)
+    assert np.array_equal(r1, r2)
+    assert np.array_equal(m.generate_step(x), m2.generate_step(x))
+    assert not np.array_equal(r0, r1)                  # the update moved the policy
+
+
+def test_update_rejects_what_it_does_not_support(cuda):
+    gcfg, _, Wg, x, y, mask, reward = _case()
+    m = _model(gcfg, Wg, "fp32", y.shape[1])
+    with pytest.raises(ValueError):
+        m.generate_step_and_update(x, y, reward[:, :-1])
+    m.build_generate(y.shape[1], optimizer='adadelta')
+    with pytest.raises(NotImplementedError):
+        m.generate_step_and_update(x, y, reward)
