@@ -56,23 +56,41 @@ static int launch_transpose(int op, int in_f32, const void* in, int64_t ld_in, i
                 : transpose_t<bf16_t, bf16_t>(in, ld_in, R, C, out, Rp, st);
 }
 
-// out[c] = sum_r in[r][c] in a fixed order (4 row lanes per column, lane sums added 0..3)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* in, int64_t ld, int R, int C, float* out) {
+// out[c] = sum_r in[r][c] in a fixed order: grid.y row chunks of `rows_per_chunk` rows (4 row lanes per column,
+// lane sums added 0..3) leave partials in part[chunk][C]; colsum_finish_kernel adds the chunks in order.
+static const int COLSUM_CHUNKS = 64;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* in, int64_t ld, int R, int C, int rows_per_chunk, float* out) {
   __shared__ float part[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
   float s = 0.f;
   if (c < C)
-    for (int r = ty; r < R; r += 4) s += in[(int64_t)r * ld + c];
+    for (int r = r0 + ty; r < r1; r += 4) s += in[(int64_t)r * ld + c];
   part[ty][tx] = s;
   __syncthreads();
-  if (ty == 0 && c < C) out[c] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+  if (ty == 0 && c < C) out[(int64_t)blockIdx.y * C + c] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
 }
-static int launch_colsum(const float* in, int64_t ld, int R, int C, float* out, hipStream_t st) {
+__global__ void colsum_finish_kernel(const float* part, int chunks, int C, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += part[(int64_t)k * C + c];
+  out[c] = s;
+}
+// scratch: COLSUM_CHUNKS * C floats (may be nullptr when R is small enough for one chunk)
+static int launch_colsum(const float* in, int64_t ld, int R, int C, float* out, float* scratch, hipStream_t st) {
   prof::Scope prof_scope(prof::OTHER, st);
   NMTGAN_REQUIRE(in && out && R > 0 && C > 0, "colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, st, in, ld, R, C, out);
+  int chunks = scratch ? std::min(COLSUM_CHUNKS, (R + 63) / 64) : 1;
+  const int per = (R + chunks - 1) / chunks;
+  chunks = (R + per - 1) / per;
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, in, ld, R, C, per, chunks > 1 ? scratch : out);
   NMTGAN_CHECK_LAUNCH("colsum");
+  if (chunks > 1) {
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, chunks, C, out);
+    NMTGAN_CHECK_LAUNCH("colsum_finish");
+  }
   return 0;
 }
 
@@ -195,21 +213,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, const float
 
 // Attention backward (dot_product_attention, common_attention.py:294-331), one workgroup per (batch, head).
 // q is the saved, already scaled query; scores of masked keys (padding bias / above the diagonal) have
-// probability exactly 0 as in the forward kernels.  P and dS live in LDS ([Tq][Tk] fp32 each).
+// probability exactly 0 as in the forward kernels.  The head slices of q, k, v, dO ([T][dh] fp32, rows padded to
+// dh+1 words so a column walk is bank-conflict free) and the two [Tq][Tk] matrices P and dS live in LDS.
 template <typename OpT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const OpT* q, const OpT* k, const OpT* v, const float* dO, int Tq, int Tk,
                                                        int d, int heads, int causal, const uint8_t* mask, float* dq,
                                                        int64_t ld_dq, float* dk, int64_t ld_dk, float* dv, int64_t ld_dv,
                                                        float dq_scale) {
   extern __shared__ float lds[];
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads, dh = d / heads, dp1 = dh + 1;
   float* P = lds;
-  float* S = lds + Tq * Tk;
-  const int b = blockIdx.x / heads, h = blockIdx.x % heads, dh = d / heads;
+  float* S = P + Tq * Tk;
+  float* Q = S + Tq * Tk;
+  float* O = Q + Tq * dp1;
+  float* K = O + Tq * dp1;
+  float* Vv = K + Tk * dp1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const OpT* qb = q + (int64_t)b * Tq * d + h * dh;
   const OpT* kb = k + (int64_t)b * Tk * d + h * dh;
   const OpT* vb = v + (int64_t)b * Tk * d + h * dh;
   const float* ob = dO + (int64_t)b * Tq * d + h * dh;
+  for (int idx = tid; idx < Tq * dh; idx += 256) {
+    const int i = idx / dh, c = idx % dh;
+    Q[i * dp1 + c] = OpTraits<OpT>::load(qb + (int64_t)i * d + c);
+    O[i * dp1 + c] = ob[(int64_t)i * d + c];
+  }
+  for (int idx = tid; idx < Tk * dh; idx += 256) {
+    const int j = idx / dh, c = idx % dh;
+    K[j * dp1 + c] = OpTraits<OpT>::load(kb + (int64_t)j * d + c);
+    Vv[j * dp1 + c] = OpTraits<OpT>::load(vb + (int64_t)j * d + c);
+  }
+  __syncthreads();
   for (int idx = tid; idx < Tq * Tk; idx += 256) {
     const int i = idx / Tk, j = idx % Tk;
     const bool valid = !(causal && j > i) && !(mask && mask[(int64_t)b * Tk + j]);
@@ -217,8 +251,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const OpT* q, const OpT* 
     if (valid) {
       s = 0.f;
       for (int c = 0; c < dh; ++c) {
-        s += OpTraits<OpT>::load(qb + (int64_t)i * d + c) * OpTraits<OpT>::load(kb + (int64_t)j * d + c);
-        dp += ob[(int64_t)i * d + c] * OpTraits<OpT>::load(vb + (int64_t)j * d + c);
+        s += Q[i * dp1 + c] * K[j * dp1 + c];
+        dp += O[i * dp1 + c] * Vv[j * dp1 + c];
       }
     }
     P[idx] = s;
@@ -251,8 +285,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const OpT* q, const OpT* 
     const int j = idx / dh, c = idx % dh;
     float av = 0.f, ak = 0.f;
     for (int i = 0; i < Tq; ++i) {
-      av += P[i * Tk + j] * ob[(int64_t)i * d + c];
-      ak += S[i * Tk + j] * OpTraits<OpT>::load(qb + (int64_t)i * d + c);
+      av += P[i * Tk + j] * O[i * dp1 + c];
+      ak += S[i * Tk + j] * Q[i * dp1 + c];
     }
     dv[((int64_t)b * Tk + j) * ld_dv + h * dh + c] = av;
     dk[((int64_t)b * Tk + j) * ld_dk + h * dh + c] = ak;
@@ -260,25 +294,42 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const OpT* q, const OpT* 
   for (int idx = tid; idx < Tq * dh; idx += 256) {
     const int i = idx / dh, c = idx % dh;
     float aq = 0.f;
-    for (int j = 0; j < Tk; ++j) aq += S[i * Tk + j] * OpTraits<OpT>::load(kb + (int64_t)j * d + c);
+    for (int j = 0; j < Tk; ++j) aq += S[i * Tk + j] * K[j * dp1 + c];
     dq[((int64_t)b * Tq + i) * ld_dq + h * dh + c] = aq * dq_scale;
   }
+}
+static size_t attn_bwd_lds(int Tq, int Tk, int dh) {
+  return ((size_t)2 * Tq * Tk + (size_t)2 * (Tq + Tk) * (dh + 1)) * sizeof(float);
+}
+static const size_t ATTN_BWD_LDS_MAX = 160 * 1024;
+template <typename OpT>
+static int attn_bwd_t(const void* q, const void* k, const void* v, const float* dO, int B, int Tq, int Tk, int d, int heads,
+                      int causal, const uint8_t* mask, float* dq, int64_t ld_dq, float* dk, int64_t ld_dk, float* dv,
+                      int64_t ld_dv, float dq_scale, size_t lds, hipStream_t st) {
+  static thread_local int raised_for_device = -1;        // opt in to > 64 KiB of dynamic LDS once per device
+  int dev = -1;
+  NMTGAN_REQUIRE(hipGetDevice(&dev) == hipSuccess, "attn_bwd: hipGetDevice failed");
+  if (raised_for_device != dev) {
+    NMTGAN_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<OpT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_BWD_LDS_MAX) == hipSuccess,
+                   "attn_bwd: cannot raise the dynamic LDS limit");
+    raised_for_device = dev;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel<OpT>, dim3(B * heads), dim3(256), lds, st, (const OpT*)q, (const OpT*)k, (const OpT*)v, dO,
+                     Tq, Tk, d, heads, causal, mask, dq, ld_dq, dk, ld_dk, dv, ld_dv, dq_scale);
+  NMTGAN_CHECK_LAUNCH("attn_bwd");
+  return 0;
 }
 static int launch_attn_bwd(int op, const void* q, const void* k, const void* v, const float* dO, int B, int Tq, int Tk,
                            int d, int heads, int causal, const uint8_t* mask, float* dq, int64_t ld_dq, float* dk,
                            int64_t ld_dk, float* dv, int64_t ld_dv, float dq_scale, hipStream_t st) {
   prof::Scope prof_scope(prof::OTHER, st);
-  const size_t lds = (size_t)2 * Tq * Tk * sizeof(float);
-  NMTGAN_REQUIRE(lds <= 64 * 1024, "attn_bwd: Tq*Tk = %d exceeds the 8192 entries two LDS score matrices hold", Tq * Tk);
-  dim3 grid(B * heads), block(256);
+  const size_t lds = attn_bwd_lds(Tq, Tk, d / heads);
+  NMTGAN_REQUIRE(lds <= ATTN_BWD_LDS_MAX, "attn_bwd: Tq=%d Tk=%d head width %d need %zu bytes of LDS (> 160 KiB)", Tq, Tk,
+                 d / heads, lds);
   if (op == NMTGAN_BF16)
-    hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, grid, block, lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, dO,
-                       Tq, Tk, d, heads, causal, mask, dq, ld_dq, dk, ld_dk, dv, ld_dv, dq_scale);
-  else
-    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, lds, st, (const float*)q, (const float*)k, (const float*)v, dO,
-                       Tq, Tk, d, heads, causal, mask, dq, ld_dq, dk, ld_dk, dv, ld_dv, dq_scale);
-  NMTGAN_CHECK_LAUNCH("attn_bwd");
-  return 0;
+    return attn_bwd_t<bf16_t>(q, k, v, dO, B, Tq, Tk, d, heads, causal, mask, dq, ld_dq, dk, ld_dk, dv, ld_dv, dq_scale, lds, st);
+  return attn_bwd_t<float>(q, k, v, dO, B, Tq, Tk, d, heads, causal, mask, dq, ld_dq, dk, ld_dk, dv, ld_dv, dq_scale, lds, st);
 }
 
 // dtable[tok[r]] += mult * dx[r]   (tf.gather backward; rows of one token collide -> float atomics)
@@ -347,7 +398,7 @@ static int dense_seg(int op, const void* A, int64_t lda, int M, int K, int N, co
   return launch_gemm(&a, st);
 }
 
-struct BwdScratch { void* dYo; void* dYT; void* XT; void* WT; };
+struct BwdScratch { void* dYo; void* dYT; void* XT; void* WT; float* colsum; };
 
 // Backward of Y = X . W + b with Wt[N][K] packed: gw.w <- dWt [N][K] fp32, gw.b <- colsum(dY), dX (optional) [M][K].
 // dY is fp32 [M][N] (dY_op == nullptr) or already in op dtype (dY_f32 == nullptr; no bias then).
@@ -356,7 +407,7 @@ static int dense_bwd(int op, const float* dY_f32, const void* dY_op, int M, int 
   const int Mp = (M + 63) / 64 * 64;
   if (gw.b) {
     NMTGAN_REQUIRE(dY_f32 != nullptr, "dense_bwd: bias gradient needs the fp32 dY");
-    NMTGAN_TRY(launch_colsum(dY_f32, N, M, N, (float*)gw.b, st));
+    NMTGAN_TRY(launch_colsum(dY_f32, N, M, N, (float*)gw.b, s.colsum, st));
   }
   const void* dYo = dY_op;
   if (dY_f32) {
@@ -391,8 +442,8 @@ static int ln_backward(const nmtgan_generator* g, const float* x, const float* y
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), (size_t)8 * d * sizeof(float), st, x, y, ln.g, dout, zero_row, M,
                      d, ds, part);
   NMTGAN_CHECK_LAUNCH("ln_bwd");
-  NMTGAN_TRY(launch_colsum(part, 2 * d, blocks, d, (float*)gln.g, st));
-  NMTGAN_TRY(launch_colsum(part + d, 2 * d, blocks, d, (float*)gln.b, st));
+  NMTGAN_TRY(launch_colsum(part, 2 * d, blocks, d, (float*)gln.g, nullptr, st));
+  NMTGAN_TRY(launch_colsum(part + d, 2 * d, blocks, d, (float*)gln.b, nullptr, st));
   return 0;
 }
 
@@ -449,6 +500,7 @@ static void carve_pg(Arena& ar, const nmtgan_generator* g, int B, int Ls, int T,
   b.s.dYT = ar.take(wideN * Mp * es);
   b.s.XT = ar.take((int64_t)4 * d * Mp * es);
   b.s.WT = ar.take(std::max<int64_t>((int64_t)4 * d * d, (int64_t)d * V) * es);
+  b.s.colsum = ar.get<float>((int64_t)COLSUM_CHUNKS * 4 * d);
 }
 
 static int check_pg(const nmtgan_generator* g, const nmtgan_generator* gr, int B, int Ls, int T) {
@@ -459,7 +511,12 @@ static int check_pg(const nmtgan_generator* g, const nmtgan_generator* gr, int B
   NMTGAN_REQUIRE(g->n_blocks > 0 && g->n_blocks <= NMTGAN_MAX_BLOCKS, "pg_grads: bad num_blocks");
   NMTGAN_REQUIRE(g->vocab_dst % 8 == 0, "pg_grads: dst_vocab_size must be a multiple of 8");
   NMTGAN_REQUIRE(B > 0 && Ls > 0 && T > 0 && Ls <= g->max_pos && T <= g->max_pos, "pg_grads: bad B/Ls/T");
-  NMTGAN_REQUIRE(T * T <= 8192 && T * Ls <= 8192 && Ls * Ls <= 8192, "pg_grads: sequence lengths above 90 are not supported");
+  {
+    const int L = std::max(T, Ls);
+    NMTGAN_REQUIRE(attn_bwd_lds(L, L, g->d / g->heads) <= ATTN_BWD_LDS_MAX,
+                   "pg_grads: max(Ls, T) = %d with head width %d exceeds the LDS budget of the attention backward", L,
+                   g->d / g->heads);
+  }
   NMTGAN_REQUIRE((const void*)g->emb_dst != g->softmax_w && g->emb_src != g->emb_dst,
                  "pg_grads: shared_embedding is not supported by the update step");
   NMTGAN_REQUIRE(gr->emb_src && gr->emb_dst && gr->softmax_w, "pg_grads: null gradient table");
