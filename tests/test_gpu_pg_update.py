@@ -133,3 +133,101 @@ def test_update_rejects_what_it_does_not_support(cuda):
     m.build_generate(y.shape[1], optimizer='adadelta')
     with pytest.raises(NotImplementedError):
         m.generate_step_and_update(x, y, reward)
+
+
+def test_production_width_gradient_is_the_directional_derivative(cuda):
+    """Size-independent property at the production width (d=512, 8 heads, V=32000, T=50; 2 blocks, 4 sentences to
+    keep it quick), fp32 tier: along u = g/||g|| the symmetric difference (L(W + eps u) - L(W - eps u)) / (2 eps)
+    equals ||g|| within 2e-2.  The learning rate is 0, so the update leaves the weights where they are."""
+    import nmt_gan_amd as N
+    from nmt_gan_amd import synthetic
+    d, blocks, heads, V, T, B = 512, 2, 8, 32000, 50, 4
+    Wg = synthetic.generator_weights(d, blocks, V, V, seed=0)
+    cfg = Cfg(hidden_units=d, num_blocks=blocks, num_heads=heads, src_vocab_size=V, dst_vocab_size=V, scale_embedding=True,
+              residual_dropout_rate=0.0, train=Cfg(shared_embedding=False), generator=Cfg(learning_rate=0.0))
+    x, y = synthetic.synthetic_batch(B, T, V, V, seed=3)
+    y[1, 20] = 3
+    x[2, 30:] = 0
+    x[2, 29] = 3
+    y, mask = N.deal_generated_samples(y)
+    reward = ((np.random.default_rng(3).random((B, T)).astype(np.float32) - np.float32(0.4)) * mask).astype(np.float32)
+
+    def loss_at(W, want_grads=False):
+        m = N.Model(cfg, precision="fp32")
+        m.build_generate(T)
+        m.init_and_restore(weights=W)
+        out = m.generate_step_and_update(x, y, reward, return_grads=want_grads)
+        if want_grads:
+            after = m.get_weights()
+            assert all(np.array_equal(after[k], np.asarray(W[k], np.float32).reshape(after[k].shape)) for k in after)
+        return out
+
+    L0, g = loss_at(Wg, True)
+    norm = float(np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in g.values())))
+    assert np.isfinite(L0) and norm > 0
+    eps = 0.02 * abs(L0) / norm
+    plus = {k: (np.asarray(Wg[k], np.float64) + eps * g[k].reshape(np.asarray(Wg[k]).shape) / norm).astype(np.float32) for k in g}
+    minus = {k: (np.asarray(Wg[k], np.float64) - eps * g[k].reshape(np.asarray(Wg[k]).shape) / norm).astype(np.float32) for k in g}
+    slope = (loss_at(plus) - loss_at(minus)) / (2 * eps)
+    assert abs(slope - norm) < 2e-2 * norm, (slope, norm, L0, eps)
+
+
+_TWO_RANK_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+z = np.load(sys.argv[4], allow_pickle=False)
+from helpers import Cfg, facade_config, tiny_cfgs
+import nmt_gan_amd as N
+gcfg, _ = tiny_cfgs(T=int(z["T"]))
+cfg = facade_config(gcfg); cfg["generator"] = Cfg(learning_rate=float(z["lr"]))
+m = N.Model(cfg, precision="fp32")
+m.build_generate(int(z["T"]))
+m.init_and_restore(weights={k[2:]: z[k] for k in z.files if k.startswith("W:")})
+loss = m.generate_step_and_update(z["x"], z["y"], z["reward"])        # every rank passes the WHOLE batch
+np.savez(sys.argv[5] + ".%d.npz" % dist.get_rank(), loss=np.float64(loss), **m.get_weights())
+dist.barrier(); dist.destroy_process_group()
+print("rank ok")
+'''
+
+
+def test_two_rank_update_is_the_tower_average(cuda, tmp_path):
+    """N > 1 path of the update (2 processes, gloo, both on cuda:0; RCCL runs the same code with backend nccl):
+    sentences split with split_tensor bounds, each rank's loss normalised by its own batch, gradients averaged
+    (model.py:121-123, 178-187, 689-722).  Both ranks end with the same weights = the oracle's RMSProp step on the
+    averaged fp64 gradients, and report the mean of the two tower losses."""
+    import os
+    import subprocess
+    import sys
+    from nmt_gan_amd.share_function import split_bounds
+    lr = 1e-2
+    gcfg, _, Wg, x, y, mask, reward = _case(reward_scale=50.0)
+    bounds = split_bounds(x.shape[0], 2)
+    parts = [O.pg_loss_and_grads(Wg, gcfg, x[bounds[r]:bounds[r + 1]], y[bounds[r]:bounds[r + 1]],
+                                 reward[bounds[r]:bounds[r + 1]]) for r in range(2)]
+    W = {k: np.array(v, np.float64) for k, v in Wg.items()}
+    G = {k: 0.5 * (parts[0][1][k] + parts[1][1][k]) for k in W}
+    O.rmsprop_apply(W, G, {k: np.ones_like(v) for k, v in W.items()}, lr)
+    inp = str(tmp_path / "in.npz")
+    np.savez(inp, x=x, y=y, reward=reward, T=y.shape[1], lr=lr, **{"W:" + k: v for k, v in Wg.items()})
+    script = tmp_path / "worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), root, port, str(r), inp, str(tmp_path / "out")],
+                              env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "rank ok" in o, o
+    got = [dict(np.load(str(tmp_path / "out") + ".%d.npz" % r, allow_pickle=False)) for r in range(2)]
+    want_loss = 0.5 * (parts[0][0] + parts[1][0])
+    for r in range(2):
+        assert abs(float(got[r]["loss"]) - want_loss) <= 1e-5 * abs(want_loss)
+    for k in W:
+        assert np.array_equal(got[0][k], got[1][k]), k
+        d_ref = W[k] - np.asarray(Wg[k], np.float64)
+        d_got = got[0][k].astype(np.float64) - np.asarray(Wg[k], np.float64)
+        tol = 2e-3 * np.abs(d_ref).max() + 2 * np.finfo(np.float32).eps * np.abs(Wg[k]).max()
+        assert np.abs(d_got - d_ref).max() <= tol, (k, np.abs(d_got - d_ref).max(), tol)
