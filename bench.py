@@ -76,9 +76,12 @@ def algorithmic_work(cfg, plan, B, Ls, es):
         "gemm_logits": ("mfma", 2 * d * V * dec_rows),
         "gemm_conv": ("mfma", conv_per_row * scored),
         "gemm_highway": ("mfma", 4 * F * F * scored),
-        # first token of every rollout: a shared prefix-logits row; rollout steps (fused path): the
-        # per-tile stats row (8 B per 64 vocabulary entries), the hidden state and the bookkeeping words
-        "sampler": ("hbm", plan.n_rows * (4 * V + 8) + step_rows * (8 * V // 64 + d * es + 40)),
+        # first token of every rollout: nmtgan_sample_rows over a prefix-logits row (the contract's 4V + 8 bytes per
+        # sampled token; the rollnum rollouts of a prefix share the row, so all but 1/rollnum of it comes from L2)
+        "sampler_rows": ("hbm", plan.n_rows * (4 * V + 8)),
+        # rollout steps (fused logits + sampling): the per-tile stats row (8 B per 64 vocabulary entries), the
+        # hidden state and the bookkeeping words - what is left of the sampler once the logits never reach HBM
+        "sampler": ("hbm", step_rows * (8 * V // 64 + d * es + 40)),
         "attn_self_step": ("hbm", N * kv_entry * self_entries),
         # the private-suffix pass alone (one wave per row): its K/V entries + the row's q in and output out
         "attn_self_private": ("hbm", N * (kv_entry * priv_entries + 2 * d * es * step_rows)),
@@ -108,6 +111,23 @@ def committed_traffic(cls, config, precision):
     hit = [v for k, v in ks.items() if re.search(TRAFFIC_KERNELS[cls], k)]
     n = sum(v["launches"] for v in hit)
     return round(sum(v["read_GB"] + v["write_GB"] for v in hit) * 1e9 / n) if n else None
+
+
+MFMA_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c2_bf16_mfma_util.json")
+
+
+def committed_mfma_busy(cls, config, precision):
+    """Matrix-core busy fraction of a GEMM class from the committed PMC summary (a separate rocprofv3 --pmc
+    SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass over one get_reward of THIS workload; tools/summarize_profile.py):
+    busy cycles / (1024 SIMDs x elapsed cycles) - utilisation at the clock the kernel ran at, where `frac` prices
+    the same kernel against the 2.4 GHz spec peak.  None when no summary matches."""
+    import re
+    if config != "c2" or precision != "bf16" or cls not in TRAFFIC_KERNELS or not os.path.exists(MFMA_FILE):
+        return None
+    ks = json.load(open(MFMA_FILE))["kernels"]
+    hit = [v for k, v in ks.items() if re.search(TRAFFIC_KERNELS[cls], k)]
+    cyc = sum(v["elapsed_cycles"] for v in hit)
+    return round(sum(v["mfma_busy_cycles"] for v in hit) / (1024.0 * cyc), 4) if cyc else None
 
 
 def cpu_baseline(cfg, Wg, Wd, x, y, seed_u):
@@ -309,12 +329,17 @@ def main():
             if tr is not None:                     # PMC bytes actually moved (committed summary) over the live time
                 row["traffic_per_launch"] = tr
                 row["traffic_GBps"] = round(tr * row["launches"] / (ms[i] * 1e-3) / 1e9, 1)
+            if row.get("bound") == "mfma":
+                mb = committed_mfma_busy(name, args.config, args.precision)
+                if mb is not None:                 # PMC matrix-core busy fraction (committed summary)
+                    row["mfma_busy_frac"] = mb
             rows[name] = row
         top = max((k for k in rows if "bound" in rows[k]), key=lambda k: rows[k]["ms"])
         r = rows[top]
         result["roofline"] = {"kernel": top, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
                               "unit": r["unit"], "frac": r["frac"],
                               "traffic": committed_traffic(top, args.config, args.precision),
+                              "mfma_busy_frac": r.get("mfma_busy_frac"),
                               "algorithmic_per_launch": round(r["algorithmic_per_step"] / r["launches"]),
                               "launches": r["launches"], "avg_launch_us": r["avg_us"],
                               "note": "HIP events around every launch of one extra (untimed) step on the SINGLE-STREAM "

@@ -382,7 +382,9 @@ int nmtgan_rmsprop_update(float* w, float* ms, float* mom, const float* grad, in
  * 8 attn_prefill (encoder + teacher-forced pass), 9 sampler, 10 add_layernorm, 11 embed,
  * 12 disc_small (gather/cast/gate/head/reduce), 13 attn_self_private (the per-row pass over the private
  * suffix keys of a rollout step when the shared prefix went through nmtgan_attn_group; class 6 then holds
- * only the shared-prefix pass).  Allocates events: never use inside timed runs.
+ * only the shared-prefix pass), 14 sampler_rows (nmtgan_sample_rows over materialised logits: the first token of
+ * every rollout; class 9 then holds the fused logits+sampling tail of the rollout steps).  Allocates events: never
+ * use inside timed runs.
  */
 int nmtgan_profile_classes(void);
 int nmtgan_profile_start(void);

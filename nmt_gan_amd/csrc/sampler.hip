@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(SampleParams p) {
 }
 
 int launch_sample_rows(const nmtgan_sample_args* a, hipStream_t st) {
-  prof::Scope prof_scope(prof::SAMPLER, st);
+  prof::Scope prof_scope(prof::SAMPLER_ROWS, st);
   NMTGAN_REQUIRE(a != nullptr, "sample: null args");
   if (a->M == 0) return 0;
   NMTGAN_REQUIRE(a->M > 0 && a->V > 0, "sample: bad M=%d V=%d", a->M, a->V);

@@ -584,6 +584,23 @@ class PreparedReward(object):
         return PreparedReward(self.model, self.disc, self.plan, cplan, self.tensors, self.host_tables, self.ws,
                               self.details, self.stream)
 
+    def capture(self):
+        """Records the whole call - every kernel, memset and the fork/join of the two streams - into ONE HIP graph
+        (the library only enqueues: no allocation, no synchronisation, no host callback); replay() then launches
+        it with a single call.  One un-captured launch runs first so that lazily created state (event pool,
+        function attributes) exists before the capture."""
+        self.launch()
+        torch.cuda.synchronize(self.model.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+            self.launch()
+        self._graph = graph
+        return self
+
+    def replay(self):
+        self._graph.replay()
+        return self.tensors["rewards"]
+
     def launch(self):
         g, dsc = self.model.c_struct, self.disc.c_struct
         st = _lib.stream_ptr() if self.stream is None else self.stream.cuda_stream

@@ -196,3 +196,22 @@ def test_get_reward_bf16_token_agreement_and_rewards(cuda, d, heads):
     print("bf16 P(real) abs err on identical rollouts: %.3g" % err)
     assert err < 2e-2
     assert np.all(r[s["mask"] == 0] == 0)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_hip_graph_replay_equals_stream_launches(cuda, setup, overlap):
+    """The library only enqueues (no allocation, synchronisation or host callback inside nmtgan_rollout_reward),
+    so a whole get_reward - both streams of the two-stream schedule included - can be captured into one HIP graph;
+    replaying it gives the bits the plain launches give."""
+    s = setup
+    m, disc = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], "bf16", T)
+    m.overlap = overlap
+    prep = m.prepare_reward(s["x"], s["xp"], s["y"], s["mask"], R, disc, T, 0.6, torch.from_numpy(s["u"]))
+    ref = prep.launch().clone()
+    torch.cuda.synchronize()
+    prep.capture()
+    prep.tensors["rewards"].zero_()
+    a = prep.replay().clone()
+    b = prep.replay().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref) and torch.equal(b, ref)

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box from the repo root):
 #   kernel-trace stats of `bench.py --overlap 0` (kernels in isolation) and of the default two-stream
-#   schedule, and separate FETCH_SIZE / WRITE_SIZE passes over one single-stream get_reward.
-# usage: tools/profile_round.sh TAG      ->  gpurun_out/prof_TAG_{serial,overlap,fetch,write}
+#   schedule, and separate FETCH_SIZE / WRITE_SIZE / matrix-core busy passes over one single-stream get_reward.
+# usage: tools/profile_round.sh TAG      ->  gpurun_out/prof_TAG_{serial,overlap,fetch,write,mfma}
 set -e
 TAG=${1:-r1}
 ROOT=$(pwd)
@@ -13,6 +13,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_overlap -- python3 $B --steps 2 --warmup 1 --no-single-stream-leg > $OUT/prof_${TAG}_overlap.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_fetch -- python3 $B --steps 1 --warmup 0 --overlap 0 > $OUT/prof_${TAG}_fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_write -- python3 $B --steps 1 --warmup 0 --overlap 0 > $OUT/prof_${TAG}_write.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_${TAG}_mfma -- python3 $B --steps 1 --warmup 0 --overlap 0 > $OUT/prof_${TAG}_mfma.log 2>&1
 cd $ROOT
 # keep only the small summary files (the traces are tens of MB)
 find $OUT/prof_${TAG}_serial $OUT/prof_${TAG}_overlap -type f ! -name "*kernel_stats.csv" -delete

@@ -1,13 +1,18 @@
 """Condense rocprofv3 outputs into the small files committed under profiles/.
 
-usage: summarize_profile.py TAG STATS_DIR [FETCH_DIR WRITE_DIR] [--steps N]
+usage: summarize_profile.py TAG STATS_DIR [FETCH_DIR WRITE_DIR] [--mfma=MFMA_DIR]
   STATS_DIR : output dir of `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`
   FETCH_DIR / WRITE_DIR : output dirs of separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over ONE
   get_reward (bench.py --steps 1 --warmup 0 --no-roofline).
 Writes profiles/TAG_kernel_stats.csv (per-kernel calls / total / average) and, with the PMC dirs,
 profiles/TAG_hbm_traffic.json: per kernel HBM bytes read / written per launch.  FETCH_SIZE and WRITE_SIZE
 are reported in KiB; on gfx950 FETCH_SIZE counts 64-byte requests as 32 bytes, hence the x2
-(MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
+(MI355X_MICROARCH.md, HBM / rocprofv3 section).
+  --mfma=MFMA_DIR : output dir of a `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass over one get_reward ->
+  profiles/TAG_mfma_util.json: per kernel the matrix-core busy fraction = SQ_VALU_MFMA_BUSY_CYCLES (summed over
+  the chip's 1024 SIMDs; 32 cycles per v_mfma_f32_32x32x16_bf16) / (1024 x elapsed cycles), elapsed cycles =
+  GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs), and the MFMA rate the busy cycles stand for at the clock
+  the kernel actually ran at (busy / 32 x 32768 flop for the bf16 32x32x16 form)."""
 import collections
 import csv
 import glob
@@ -63,5 +68,33 @@ def main():
         print("wrote", tag + "_hbm_traffic.json")
 
 
+def mfma_summary(tag, d, out_dir):
+    agg = collections.defaultdict(lambda: {"launches": 0, "busy": 0.0, "gui": 0.0})
+    for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+        k = short(r["Kernel_Name"])
+        if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+            agg[k]["busy"] += float(r["Counter_Value"])
+            agg[k]["launches"] += 1
+        elif r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            agg[k]["gui"] += float(r["Counter_Value"])
+    out = {}
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["busy"]):
+        if v["busy"] <= 0 or v["gui"] <= 0:
+            continue
+        cycles = v["gui"] / 8.0
+        out[k] = {"launches": v["launches"], "mfma_busy_cycles": round(v["busy"]), "elapsed_cycles": round(cycles),
+                  "mfma_busy_frac": round(v["busy"] / (1024.0 * cycles), 4),
+                  "bf16_32x32x16_TFLOP": round(v["busy"] / 32.0 * 32768 / 1e12, 3)}
+    json.dump({"note": "one get_reward (C2, bf16, single-stream schedule); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
+                       "(1024 SIMDs x GRBM_GUI_ACTIVE / 8); 1.0 = every matrix core issuing back to back = the dense "
+                       "bf16 peak AT THE CLOCK THE KERNEL RAN AT (DVFS holds these GEMMs near 1.5 GHz, not 2.4)",
+               "kernels": out}, open(os.path.join(out_dir, tag + "_mfma_util.json"), "w"), indent=1)
+    print("wrote", tag + "_mfma_util.json")
+
+
 if __name__ == "__main__":
+    for a in sys.argv[1:]:
+        if a.startswith("--mfma="):
+            mfma_summary([b for b in sys.argv[1:] if not b.startswith("--")][0], a.split("=", 1)[1],
+                         os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
     main()
