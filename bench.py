@@ -186,6 +186,10 @@ def main():
                     help="1: two-stream schedule (discriminator scoring of finished rollouts overlaps the decode steps)")
     ap.add_argument("--no-single-stream-leg", action="store_true",
                     help="skip the extra timing of the same workload on the single-stream schedule")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 rehearsal on a box with fewer GPUs than ranks: gloo backend, ranks share the visible GPUs "
+                         "(device = local_rank %% device_count).  Exercises the sharding / gather / timing code of the "
+                         "multi-GPU run; the JSON line is marked \"rehearsal\": true and is not a measurement")
     ap.add_argument("--aux-wgs", type=int, default=0)
     ap.add_argument("--aux-min-rows", type=int, default=0)
     args = ap.parse_args()
@@ -198,9 +202,13 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    if args.rehearse:
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 and args.rehearse:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
 
     import nmt_gan_amd as N
@@ -260,7 +268,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert bool(torch.isfinite(out).all())
@@ -294,6 +302,8 @@ def main():
     }
     if single_ms is not None:
         result["single_stream_ms_per_step"] = round(single_ms, 2)
+    if args.rehearse:
+        result["rehearsal"] = True
 
     if rank == 0 and world == 1 and not args.no_roofline:
         ncls = _lib.lib.nmtgan_profile_classes()

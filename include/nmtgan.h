@@ -360,7 +360,8 @@ int nmtgan_teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, co
  *   is overwritten.  loss: 1 float on the device; p_target (optional): [B][T] probability of Y[b,t].
  *   x [B][Ls], x_pad [B][Ls] (1 where x == 0), y [B][T], dec_in = shift_right(y), reward [B][T].
  *   Residual dropout is neutralised as on the rollout path; shared_embedding models are rejected;
- *   Ls, T <= 90 (the attention backward holds two score matrices in LDS).
+ *   max(Ls, T) is bounded by the 160 KiB of LDS the attention backward keeps its head slices and two score
+ *   matrices in (90 at a head width of 64).
  * nmtgan_rmsprop_update: dense ApplyRMSProp over n contiguous parameters (ms += (g*g - ms)(1 - decay);
  *   mom = mom*momentum + lr*g/sqrt(ms + eps); w -= mom) with g = grad * grad_scale (the tower average of
  *   model.py:689-722); mom may be NULL (momentum 0); w_op (optional) receives the updated parameters in
@@ -372,6 +373,11 @@ int nmtgan_pg_grads(const nmtgan_generator* g, const nmtgan_generator* grads, co
                     float* p_target, void* workspace, size_t workspace_bytes, void* stream);
 int nmtgan_rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay,
                           float momentum, float eps, float grad_scale, void* w_op, int op_dtype, void* stream);
+/* tf.train.AdadeltaOptimizer() - the only other optimizer build_generate can select (model.py:111-119; defaults
+ * lr 0.001, rho 0.95, eps 1e-8, both slots start at 0): accum = rho accum + (1-rho) g^2; upd = sqrt(accum_update + eps)
+ * rsqrt(accum + eps) g; accum_update = rho accum_update + (1-rho) upd^2; w -= lr upd.  Same conventions as above. */
+int nmtgan_adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr,
+                           float rho, float eps, float grad_scale, void* w_op, int op_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hook (no counterpart in the reference; used by bench.py's roofline leg only).

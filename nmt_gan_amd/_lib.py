@@ -132,6 +132,7 @@ EXPORTS = {
     "nmtgan_pg_grads": (i32, [C.POINTER(Generator), C.POINTER(Generator), vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
                               sz, vp]),
     "nmtgan_rmsprop_update": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]),
+    "nmtgan_adadelta_update": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp]),
     "nmtgan_profile_classes": (i32, []),
     "nmtgan_profile_start": (i32, []),
     "nmtgan_profile_stop": (i32, [C.POINTER(f64), C.POINTER(i64), i32]),

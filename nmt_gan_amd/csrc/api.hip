@@ -49,6 +49,8 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
              size_t ws_bytes, hipStream_t st);
 int rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay, float momentum,
                    float eps, float grad_scale, void* w_op, int op_dtype, hipStream_t st);
+int adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr, float rho,
+                    float eps, float grad_scale, void* w_op, int op_dtype, hipStream_t st);
 }  // namespace nmtgan
 
 using namespace nmtgan;
@@ -171,6 +173,10 @@ int nmtgan_pg_grads(const nmtgan_generator* g, const nmtgan_generator* grads, co
 int nmtgan_rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay,
                           float momentum, float eps, float grad_scale, void* w_op, int op_dtype, void* stream) {
   return rmsprop_update(w, ms, mom, grad, n, lr, decay, momentum, eps, grad_scale, w_op, op_dtype, (hipStream_t)stream);
+}
+int nmtgan_adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr, float rho,
+                           float eps, float grad_scale, void* w_op, int op_dtype, void* stream) {
+  return adadelta_update(w, accum, accum_update, grad, n, lr, rho, eps, grad_scale, w_op, op_dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -377,6 +377,41 @@ int rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n
   return 0;
 }
 
+// tf.train.AdadeltaOptimizer() (model.py:115-116: learning_rate 0.001, rho 0.95, epsilon 1e-8, both slots 0), dense:
+//   accum = rho accum + (1 - rho) g^2;  upd = sqrt(accum_update + eps) * rsqrt(accum + eps) * g;
+//   accum_update = rho accum_update + (1 - rho) upd^2;  w -= lr upd
+template <typename OpT>
+__global__ void adadelta_kernel(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr,
+                                float rho, float eps, float grad_scale, OpT* w_op) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = grad[i] * grad_scale;
+  const float a = accum[i] * rho + g * g * (1.0f - rho);
+  accum[i] = a;
+  const float upd = sqrtf(accum_update[i] + eps) * rsqrtf(a + eps) * g;
+  accum_update[i] = accum_update[i] * rho + upd * upd * (1.0f - rho);
+  const float nw = w[i] - lr * upd;
+  w[i] = nw;
+  if (w_op) OpTraits<OpT>::store(w_op + i, nw);
+}
+
+int adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr, float rho,
+                    float eps, float grad_scale, void* w_op, int op_dtype, hipStream_t st) {
+  prof::Scope prof_scope(prof::OTHER, st);
+  if (n == 0) return 0;
+  NMTGAN_REQUIRE(w && accum && accum_update && grad && n > 0, "adadelta_update: null pointer");
+  NMTGAN_REQUIRE(lr >= 0.f && rho >= 0.f && rho <= 1.f && eps > 0.f, "adadelta_update: bad hyper-parameter");
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (w_op && op_dtype == NMTGAN_BF16)
+    hipLaunchKernelGGL(adadelta_kernel<bf16_t>, grid, block, 0, st, w, accum, accum_update, grad, n, lr, rho, eps, grad_scale,
+                       (bf16_t*)w_op);
+  else
+    hipLaunchKernelGGL(adadelta_kernel<float>, grid, block, 0, st, w, accum, accum_update, grad, n, lr, rho, eps, grad_scale,
+                       (float*)(op_dtype == NMTGAN_F32 ? w_op : nullptr));
+  NMTGAN_CHECK_LAUNCH("adadelta");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ host helpers
 static int gemm_f32out(int op, const void* A, int64_t lda, int M, int K, int N, const void* Wt, const float* bias,
                        float* out, int64_t ldo, hipStream_t st) {

@@ -343,12 +343,10 @@ class Model(object):
     def generate_step_and_update(self, sentence_x, sentence_y, reward, *, return_grads=False):
         """Reference: model.py:273-276 -> the loss half of build_generate (model.py:178-190): teacher-forced
         decoder over shift_right(Y), gan_output loss -sum p(y_t) reward_t / B (model.py:649-666), gradients of
-        every trainable variable, RMSProp(config.generator.learning_rate) update.  Returns the loss.
+        every trainable variable, RMSProp(config.generator.learning_rate) or Adadelta() update.  Returns the loss.
         With torch.distributed initialised the sentences are split across ranks like the reference's towers
         (split_tensor), every rank's loss is normalised by its own batch and gradients are averaged
         (average_gradients, model.py:689-722) with one RCCL all-reduce of the flat gradient buffer."""
-        if self.g_optimizer != 'rmsprop':
-            raise NotImplementedError("generate_step_and_update: only the RMSProp optimizer is built (adadelta is not)")
         x = np.ascontiguousarray(np.asarray(sentence_x), dtype=np.int32)
         y = np.ascontiguousarray(np.asarray(sentence_y), dtype=np.int32)
         r = np.ascontiguousarray(np.asarray(reward), dtype=np.float32)
@@ -391,9 +389,16 @@ class Model(object):
             for name, (kind, o, n) in tr["index"].items():
                 a, shp = host[o:o + n], tr["shapes"][name]
                 grads[name] = np.ascontiguousarray((a.reshape(shp[-1], shp[-2]).T if kind == "mat" else a).reshape(shp))
-        lr = float(_cfg_get(self.config, "generator.learning_rate", 1e-5))
-        check(lib.nmtgan_rmsprop_update(ptr(tr["master"]), ptr(tr["ms"]), None, ptr(tr["grad"]), tr["n"], lr, 0.9, 0.0,
-                                        1e-10, 1.0 / world, ptr(tr["op"]), self._op, st), "nmtgan_rmsprop_update")
+        if self.g_optimizer == 'adadelta':             # tf.train.AdadeltaOptimizer(): its own defaults, model.py:115-116
+            if "accum" not in tr:
+                tr["accum"], tr["accum_update"] = torch.zeros_like(tr["master"]), torch.zeros_like(tr["master"])
+            check(lib.nmtgan_adadelta_update(ptr(tr["master"]), ptr(tr["accum"]), ptr(tr["accum_update"]), ptr(tr["grad"]),
+                                             tr["n"], 0.001, 0.95, 1e-8, 1.0 / world, ptr(tr["op"]), self._op, st),
+                  "nmtgan_adadelta_update")
+        else:
+            lr = float(_cfg_get(self.config, "generator.learning_rate", 1e-5))
+            check(lib.nmtgan_rmsprop_update(ptr(tr["master"]), ptr(tr["ms"]), None, ptr(tr["grad"]), tr["n"], lr, 0.9, 0.0,
+                                            1e-10, 1.0 / world, ptr(tr["op"]), self._op, st), "nmtgan_rmsprop_update")
         tr["steps"] += 1
         torch.cuda.synchronize(self.device)
         out = float(loss.item())

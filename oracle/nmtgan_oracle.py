@@ -496,6 +496,17 @@ def rmsprop_apply(W: Dict[str, np.ndarray], G: Dict[str, np.ndarray], ms: Dict[s
         W[k] -= step.astype(W[k].dtype)
 
 
+def adadelta_apply(W, G, accum, accum_update, lr: float = 0.001, rho: float = 0.95, epsilon: float = 1e-8):
+    """tf.train.AdadeltaOptimizer() defaults (model.py:115-116), dense ApplyAdadelta as recalled from TF 1.x
+    (unverifiable offline; both slots start at zero).  In place."""
+    for k in W:
+        g = np.asarray(G[k], W[k].dtype)
+        accum[k][...] = accum[k] * rho + g * g * (1.0 - rho)
+        upd = np.sqrt(accum_update[k] + epsilon) / np.sqrt(accum[k] + epsilon) * g
+        accum_update[k][...] = accum_update[k] * rho + upd * upd * (1.0 - rho)
+        W[k] -= lr * upd
+
+
 # --------------------------------------------------------------------------- discriminator
 def _conv_bn_relu_max(e, Wd, scope):
     """cnn_layer.conv_op + max_pool (cnn_discriminator.py:88-109, 22-33, 469).  e: [B,T,E]."""

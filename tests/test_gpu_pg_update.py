@@ -130,9 +130,38 @@ def test_update_rejects_what_it_does_not_support(cuda):
     m = _model(gcfg, Wg, "fp32", y.shape[1])
     with pytest.raises(ValueError):
         m.generate_step_and_update(x, y, reward[:, :-1])
-    m.build_generate(y.shape[1], optimizer='adadelta')
+    import nmt_gan_amd as N
+    cfg = facade_config(gcfg)
+    cfg["train"] = Cfg(shared_embedding=True)
+    shared = N.Model(cfg, precision="fp32")
+    shared.build_generate(y.shape[1])
+    Ws = dict(Wg, **{"embedding/shared/kernel": Wg["embedding/softmax/kernel"]})
+    shared.init_and_restore(weights=Ws)
     with pytest.raises(NotImplementedError):
-        m.generate_step_and_update(x, y, reward)
+        shared.generate_step_and_update(x, y, reward)
+
+
+def test_fp32_two_adadelta_updates_match_oracle(cuda):
+    """build_generate(optimizer='adadelta') (model.py:115-116): two steps of tf.train.AdadeltaOptimizer() defaults
+    against the oracle's restatement, same tolerances as the RMSProp test."""
+    gcfg, _, Wg, x, y, mask, reward = _case(reward_scale=50.0)
+    W = {k: np.array(v, np.float64) for k, v in Wg.items()}
+    acc, acc_u = {k: np.zeros_like(v) for k, v in W.items()}, {k: np.zeros_like(v) for k, v in W.items()}
+    ref_losses = []
+    for _ in range(2):
+        l, G = O.pg_loss_and_grads(W, gcfg, x, y, reward)
+        ref_losses.append(l)
+        O.adadelta_apply(W, G, acc, acc_u)
+    m = _model(gcfg, Wg, "fp32", y.shape[1])
+    m.build_generate(y.shape[1], optimizer='adadelta')
+    losses = [m.generate_step_and_update(x, y, reward) for _ in range(2)]
+    assert abs(losses[1] - ref_losses[1]) <= 1e-4 * abs(ref_losses[1])
+    got = m.get_weights()
+    for k in W:
+        d_ref = W[k] - np.asarray(Wg[k], np.float64)
+        d_got = got[k].astype(np.float64) - np.asarray(Wg[k], np.float64)
+        tol = 2e-3 * np.abs(d_ref).max() + 2 * np.finfo(np.float32).eps * np.abs(Wg[k]).max()
+        assert np.abs(d_got - d_ref).max() <= tol, (k, np.abs(d_got - d_ref).max(), tol)
 
 
 def test_production_width_gradient_is_the_directional_derivative(cuda):

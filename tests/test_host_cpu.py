@@ -77,6 +77,20 @@ def test_entry_points_validate_before_launch():
     t = _lib.AttnArgs()
     t.M, t.d, t.heads = 2, 96, 4                                   # d % 64 != 0
     assert _lib.lib.nmtgan_attn_rows(C.byref(t), None) != 0
+    g = _lib.Generator()                                           # update step: shapes are checked before any launch
+    g.op_dtype, g.d, g.heads, g.n_blocks, g.vocab_src, g.vocab_dst, g.max_pos = 0, 64, 4, 2, 512, 508, 256
+    assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 8, 8) == 0
+    assert b"multiple of 8" in _lib.lib.nmtgan_last_error()
+    g.vocab_dst = 512
+    assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 8, 300) == 0      # T beyond the timing table
+    g.emb_src, g.emb_dst, g.softmax_w = 4096, 8192, 8192                        # shared embedding/softmax table
+    assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 8, 8) == 0
+    assert b"shared_embedding" in _lib.lib.nmtgan_last_error()
+    g.softmax_w = 12288
+    assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 8, 8) > 0
+    assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 200, 200) == 0    # LDS budget of the attention backward
+    assert _lib.lib.nmtgan_rmsprop_update(None, None, None, None, 16, 1e-5, 0.9, 0.0, 1e-10, 1.0, None, 0, None) != 0
+    assert _lib.lib.nmtgan_adadelta_update(4096, 4096, 4096, 4096, 16, 1e-3, 1.5, 1e-8, 1.0, None, 0, None) != 0
     with pytest.raises(_lib.NmtGanError):
         _lib.check(-2, "x")
 
