@@ -962,7 +962,26 @@ bool gemm_stats_supported(int op_dtype, int V, int K) {
   return V % 64 == 0 && V <= 65536 && (K * es) % BKB == 0 && (K * es) / BKB >= 4;   // <= 1024 vocabulary tiles
 }
 
+static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st);
+// NMTGAN_TRACE_GEMM=1: time every GEMM call with a pair of events and a synchronise, print shape and time
+// (diagnosis only - it serialises the stream)
 int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st) {
+  static const bool trace = [] { const char* e = getenv("NMTGAN_TRACE_GEMM"); return e && atoi(e) != 0; }();
+  if (!trace || !a) return launch_gemm_impl(a, st);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, st);
+  const int rc = launch_gemm_impl(a, st);
+  (void)hipEventRecord(e1, st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  fprintf(stderr, "GEMM epi=%d M=%d N=%d K=%d a_group=%d ldw=%lld us=%.1f tflops=%.1f\n", a->epilogue, a->M, a->N, a->K,
+          a->a_group, (long long)a->ldw, ms * 1e3, 2.0 * a->M * a->N * a->K / (ms * 1e-3) / 1e12);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
   prof::Scope prof_scope(prof::GEMM_PROJ, st);
   NMTGAN_REQUIRE(a != nullptr, "gemm: null args");
   NMTGAN_REQUIRE(a->op_dtype == NMTGAN_BF16 || a->op_dtype == NMTGAN_F32, "gemm: bad op_dtype %d", a->op_dtype);
