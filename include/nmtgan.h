@@ -364,20 +364,59 @@ int nmtgan_teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, co
  *   matrices in (90 at a head width of 64).
  * nmtgan_rmsprop_update: dense ApplyRMSProp over n contiguous parameters (ms += (g*g - ms)(1 - decay);
  *   mom = mom*momentum + lr*g/sqrt(ms + eps); w -= mom) with g = grad * grad_scale (the tower average of
- *   model.py:689-722); mom may be NULL (momentum 0); w_op (optional) receives the updated parameters in
- *   op_dtype (the MFMA operand copy of a bf16 model).
+ *   model.py:689-722), then clipped to [-grad_clip, grad_clip] when grad_clip > 0 (the discriminator's
+ *   average_clip_gradient_by_value, share_function.py:413-441); mom may be NULL (momentum 0); w_op (optional)
+ *   receives the updated parameters in op_dtype (the MFMA operand copy of a bf16 model).
  */
 size_t nmtgan_pg_workspace_bytes(const nmtgan_generator* g, int B, int Ls, int T);
 int nmtgan_pg_grads(const nmtgan_generator* g, const nmtgan_generator* grads, const int32_t* x, const uint8_t* x_pad,
                     const int32_t* y, const int32_t* dec_in, const float* reward, int B, int Ls, int T, float* loss,
                     float* p_target, void* workspace, size_t workspace_bytes, void* stream);
 int nmtgan_rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay,
-                          float momentum, float eps, float grad_scale, void* w_op, int op_dtype, void* stream);
+                          float momentum, float eps, float grad_scale, float grad_clip, void* w_op, int op_dtype,
+                          void* stream);
 /* tf.train.AdadeltaOptimizer() - the only other optimizer build_generate can select (model.py:111-119; defaults
  * lr 0.001, rho 0.95, eps 1e-8, both slots start at 0): accum = rho accum + (1-rho) g^2; upd = sqrt(accum_update + eps)
  * rsqrt(accum + eps) g; accum_update = rho accum_update + (1-rho) upd^2; w -= lr upd.  Same conventions as above. */
 int nmtgan_adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr,
                            float rho, float eps, float grad_scale, void* w_op, int op_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Discriminator training step: one iteration of DisCNN.train (cnn_discriminator.py:664-691),
+ * i.e. sess.run([train_optm, train_loss, train_accuracy, train_grads_and_vars]) for one tower: build_model
+ * (cnn_discriminator.py:248-345) in TRAINING mode - BatchNorm with batch moments over (sentence, window) per filter,
+ * moving statistics moved in place with decay 0.9 (conv_batch_norm, :22-33), dropout keep 1.0 (train() feeds
+ * drop_prob = 1.0) - softmax cross-entropy, and the gradients of sum(losses) (compute_gradients on the per-example
+ * vector, :334) of every trainable variable.
+ * `d` supplies the MFMA-operand copies the forward reads (tables, conv filters Wt[n][w*E], highway Wt[Fp][Fp]) and
+ * the fp32 head; `p` the fp32 per-filter vectors of each tower, concatenated over the widths in filter order ([F]
+ * each: conv bias, BN gamma/beta, BN moving mean/variance - the moving statistics are UPDATED); `grads` has the
+ * same shape and receives fp32 gradients in the packed layouts (emb [V][E], conv_w[i] Wt[n][w*E], conv_b/gamma/beta
+ * [F], hw_* Wt[Fp][Fp], head_w [2][2Fp], head_b [2]; its moving_* fields are ignored).
+ * x / xs: [M][T] batch-major ids of the target / source tower; labels [M][2] one-hot rows; loss (mean of the
+ * per-example losses, :343) and accuracy (:326-327): 1 float each on the device.
+ * nmtgan_disc_fold_bn recomputes the inference constants (conv_scale / conv_shift of nmtgan_disc_tower) from the
+ * trained vectors; nmtgan_clip_values is the one-off weight clip to [-1, 1] after the first step (:583-591, 690).
+ */
+typedef struct {
+  float* emb;                                  /* [V][E] */
+  float* conv_w[NMTGAN_MAX_WIDTHS];            /* Wt[n_w][w*E] */
+  float* conv_b; float* gamma; float* beta;    /* [F] each, widths concatenated */
+  float* moving_mean; float* moving_var;       /* [F] each, not trainable */
+  float* hw_out; float* hw_tr;                 /* Wt[Fp][Fp] */
+} nmtgan_disc_tower_params;
+typedef struct {
+  nmtgan_disc_tower_params tgt, src;
+  float* head_w;                               /* [2][2*Fp] */
+  float* head_b;                               /* [2] */
+} nmtgan_disc_params;
+size_t nmtgan_disc_train_workspace_bytes(const nmtgan_discriminator* d, int M);
+int nmtgan_disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p, const nmtgan_disc_params* grads,
+                            const int32_t* x, const int32_t* xs, const float* labels, int M, float* loss,
+                            float* accuracy, void* workspace, size_t workspace_bytes, void* stream);
+int nmtgan_disc_fold_bn(const float* conv_b, const float* gamma, const float* beta, const float* moving_mean,
+                        const float* moving_var, int n, float* scale, float* shift, void* stream);
+int nmtgan_clip_values(float* w, int64_t n, float lo, float hi, void* w_op, int op_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hook (no counterpart in the reference; used by bench.py's roofline leg only).

@@ -94,6 +94,15 @@ class Discriminator(C.Structure):
                 ("F", i32), ("Fp", i32), ("tgt", DiscTower), ("src", DiscTower), ("head_w", vp), ("head_b", vp)]
 
 
+class DiscTowerParams(C.Structure):
+    _fields_ = [("emb", vp), ("conv_w", vp * MAX_WIDTHS), ("conv_b", vp), ("gamma", vp), ("beta", vp),
+                ("moving_mean", vp), ("moving_var", vp), ("hw_out", vp), ("hw_tr", vp)]
+
+
+class DiscParams(C.Structure):
+    _fields_ = [("tgt", DiscTowerParams), ("src", DiscTowerParams), ("head_w", vp), ("head_b", vp)]
+
+
 class RewardPlan(C.Structure):
     _fields_ = [("B", i32), ("Ls", i32), ("T", i32), ("rollnum", i32), ("n_rows", i32), ("n_steps", i32),
                 ("live", vp), ("step_off_host", vp), ("step_off", vp),
@@ -131,8 +140,13 @@ EXPORTS = {
     "nmtgan_pg_workspace_bytes": (sz, [C.POINTER(Generator), i32, i32, i32]),
     "nmtgan_pg_grads": (i32, [C.POINTER(Generator), C.POINTER(Generator), vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
                               sz, vp]),
-    "nmtgan_rmsprop_update": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]),
+    "nmtgan_rmsprop_update": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, i32, vp]),
     "nmtgan_adadelta_update": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp]),
+    "nmtgan_disc_train_workspace_bytes": (sz, [C.POINTER(Discriminator), i32]),
+    "nmtgan_disc_train_grads": (i32, [C.POINTER(Discriminator), C.POINTER(DiscParams), C.POINTER(DiscParams), vp, vp, vp, i32,
+                                      vp, vp, vp, sz, vp]),
+    "nmtgan_disc_fold_bn": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp]),
+    "nmtgan_clip_values": (i32, [vp, i64, f32, f32, vp, i32, vp]),
     "nmtgan_profile_classes": (i32, []),
     "nmtgan_profile_start": (i32, []),
     "nmtgan_profile_stop": (i32, [C.POINTER(f64), C.POINTER(i64), i32]),

@@ -1,9 +1,10 @@
 """DisCNN facade: the inference surface of the reference's cnn_discriminator.DisCNN that
 Model.get_reward drives (model.py:311-313), backed by libnmtgan_hip.so.
 
-Only inference is in scope: the two-tower multi-width CNN + highway + 2-way
-softmax of build_discriminator_body (cnn_discriminator.py:440-522) with BatchNorm in
-moving-statistics mode.  Training (build_train_model / train) is out of scope and raises.
+Inference: the two-tower multi-width CNN + highway + 2-way softmax of
+build_discriminator_body (cnn_discriminator.py:440-522) with BatchNorm in moving-statistics mode.
+Training: train_step() is one iteration of DisCNN.train (cnn_discriminator.py:664-691) on a
+batch the caller supplies; the file iterators around it (train(), :593-704) are data pipeline and stay out.
 """
 from __future__ import annotations
 
@@ -71,6 +72,9 @@ class DisCNN(object):
         self._keep = []            # device tensors kept alive for the C struct
         self._c = None
         self._ws = None
+        self._W_src, self._train = None, None
+        self.optimizer_name = optimizer          # cnn_discriminator.py:153-166; RMSPropOptimizer(0.0001) for 'rmsprop'
+        self.learning_rate = 1e-4
         self.reload = bool(reload)
         if self.reload:                # cnn_discriminator.py:209-217: saver.restore(sess, saveto) in the constructor
             self.restore(saveto)
@@ -134,7 +138,230 @@ class DisCNN(object):
         c.head_w = ptr(dv(head, torch.float32))
         c.head_b = ptr(dv(np.asarray(W[s + "model_self/b"], np.float32), torch.float32))
         self._keep, self._c = keep, c
+        self._W_src, self._train = W, None
         return self
+
+    # ------------------------------------------------------------------ training (row f-4)
+    def _tf_names(self):
+        """(tower key, TF name prefix pieces) of both towers."""
+        s = self.scope + "/"
+        return (("tgt", s + "model_self/embeddingtable", s + "conv_maxpool-%d/", s + "output_lin_0/weights",
+                 s + "transform_lin_0/weights"),
+                ("src", s + "model_self/embeddingtable_s", s + "conv_s_maxpool-%d/", s + "output_s_lin_0/weights",
+                 s + "transform_s_lin_0/weights"))
+
+    def _enable_training(self):
+        """Re-homes the weights for train_step(): one flat fp32 master buffer with every TRAINABLE tensor in its
+        packed layout (tables [V][E], conv filters Wt[n][w*E], per-filter vectors concatenated over the widths,
+        highway Wt[Fp][Fp] zero padded, head [2][2Fp]) at 256-byte aligned offsets, a flat gradient buffer and a flat
+        RMSProp accumulator with the same offsets (one optimizer launch, one all-reduce), a flat bf16 operand copy for
+        a bf16 model, and the BatchNorm moving statistics + the folded inference constants beside them."""
+        if self._train is not None:
+            return self._train
+        W = self._W_src
+        if W is None:
+            raise RuntimeError("DisCNN: load_weights() has not been called")
+        dev, E, F, Fp = self.device, self.dim_word, self.num_filters_total, self.Fp
+        chunks, off = [], 0
+
+        def add(key, arr, tf_name, kind):
+            nonlocal off
+            a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+            chunks.append((key, tf_name, kind, off, a))
+            off += (a.size + 63) // 64 * 64
+
+        moving = {}
+        for tkey, emb_name, conv_fmt, out_name, tr_name in self._tf_names():
+            add((tkey, "emb"), np.asarray(W[emb_name], np.float32), emb_name, "tab")
+            vecs = {k: [] for k in ("b", "gamma", "beta", "moving_mean", "moving_variance")}
+            for w, n in zip(self.filter_sizes, self.num_filters):
+                p = conv_fmt % w
+                add((tkey, "conv_w", w), np.asarray(W[p + "self_model/W"], np.float32).reshape(w * E, n).T,
+                    p + "self_model/W", "conv")
+                vecs["b"].append(np.asarray(W[p + "self_model/b"], np.float32))
+                for k in ("gamma", "beta", "moving_mean", "moving_variance"):
+                    vecs[k].append(np.asarray(W[p + "conv_batch_norm/bn/" + k], np.float32))
+            add((tkey, "conv_b"), np.concatenate(vecs["b"]), conv_fmt + "self_model/b", "vec")
+            add((tkey, "gamma"), np.concatenate(vecs["gamma"]), conv_fmt + "conv_batch_norm/bn/gamma", "vec")
+            add((tkey, "beta"), np.concatenate(vecs["beta"]), conv_fmt + "conv_batch_norm/bn/beta", "vec")
+            moving[tkey] = (np.concatenate(vecs["moving_mean"]), np.concatenate(vecs["moving_variance"]))
+            for key, name in (("hw_out", out_name), ("hw_tr", tr_name)):
+                Wh = np.zeros((Fp, Fp), np.float32)
+                Wh[:F, :F] = np.asarray(W[name], np.float32).T
+                add((tkey, key), Wh, name, "hw")
+        Wh = np.asarray(W[self.scope + "/model_self/W"], np.float32)
+        head = np.zeros((2, 2 * Fp), np.float32)
+        for cls in range(2):
+            head[cls, :F] = Wh[:F, cls]
+            head[cls, Fp:Fp + F] = Wh[F:, cls]
+        add(("head_w",), head, self.scope + "/model_self/W", "head")
+        add(("head_b",), np.asarray(W[self.scope + "/model_self/b"], np.float32), self.scope + "/model_self/b", "vec1")
+        host = np.zeros(off, np.float32)
+        for _, _, _, o, a in chunks:
+            host[o:o + a.size] = a
+        master = torch.from_numpy(host).to(dev)
+        grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        ms = torch.ones(off, dtype=torch.float32, device=dev)
+        opc = master.to(torch.bfloat16) if self.precision == "bf16" else None
+        stats = {t: (torch.from_numpy(m.copy()).to(dev), torch.from_numpy(v.copy()).to(dev)) for t, (m, v) in moving.items()}
+        fold = {t: (torch.zeros(F, dtype=torch.float32, device=dev), torch.zeros(F, dtype=torch.float32, device=dev))
+                for t in moving}
+        c = _lib.Discriminator.from_buffer_copy(self._c)
+        pc, gc = _lib.DiscParams(), _lib.DiscParams()
+        index, col_off = {}, np.concatenate([[0], np.cumsum(self.num_filters)]).astype(int)
+        for key, tf_name, kind, o, a in chunks:
+            mptr, gptr = master.data_ptr() + 4 * o, grad.data_ptr() + 4 * o
+            optr = (opc.data_ptr() + 2 * o) if opc is not None else mptr
+            index[key] = (tf_name, kind, o, a.size)
+            if key[0] in ("tgt", "src"):
+                ct, pt, gt = getattr(c, key[0]), getattr(pc, key[0]), getattr(gc, key[0])
+                if key[1] == "emb":
+                    ct.emb, pt.emb, gt.emb = optr, mptr, gptr
+                elif key[1] == "conv_w":
+                    i = self.filter_sizes.index(key[2])
+                    ct.conv_w[i], pt.conv_w[i], gt.conv_w[i] = optr, mptr, gptr
+                elif key[1] in ("hw_out", "hw_tr"):
+                    setattr(ct, key[1], optr), setattr(pt, key[1], mptr), setattr(gt, key[1], gptr)
+                else:
+                    setattr(pt, key[1], mptr), setattr(gt, key[1], gptr)
+            elif key[0] == "head_w":
+                c.head_w, pc.head_w, gc.head_w = mptr, mptr, gptr
+            else:
+                c.head_b, pc.head_b, gc.head_b = mptr, mptr, gptr
+        for t in ("tgt", "src"):
+            pt, ct = getattr(pc, t), getattr(c, t)
+            pt.moving_mean, pt.moving_var = stats[t][0].data_ptr(), stats[t][1].data_ptr()
+            for i in range(len(self.filter_sizes)):
+                ct.conv_scale[i] = fold[t][0].data_ptr() + 4 * int(col_off[i])
+                ct.conv_shift[i] = fold[t][1].data_ptr() + 4 * int(col_off[i])
+        self._keep = [master, grad, ms, stats, fold] + ([opc] if opc is not None else [])
+        self._c = c
+        self._train = dict(master=master, grad=grad, ms=ms, op=opc, pc=pc, gc=gc, index=index, n=off, stats=stats, fold=fold,
+                           steps=0, loss=torch.zeros(1, dtype=torch.float32, device=dev),
+                           acc=torch.zeros(1, dtype=torch.float32, device=dev))
+        self._fold_bn()
+        return self._train
+
+    def _fold_bn(self):
+        tr, F = self._train, self.num_filters_total
+        for t in ("tgt", "src"):
+            pt = getattr(tr["pc"], t)
+            check(lib.nmtgan_disc_fold_bn(pt.conv_b, pt.gamma, pt.beta, pt.moving_mean, pt.moving_var, F,
+                                          ptr(tr["fold"][t][0]), ptr(tr["fold"][t][1]), _lib.stream_ptr()), "nmtgan_disc_fold_bn")
+
+    def train_step(self, x, y, xs, *, return_grads=False):
+        """One iteration of DisCNN.train (cnn_discriminator.py:664-691) on one batch: x [max_len, B] target ids,
+        y [2, B] one-hot labels, xs [max_len, B] source ids (the arrays dis_three_length_prepare feeds), dropout keep
+        1.0 as train() feeds it.  Forward in training mode (BatchNorm batch moments, moving statistics moved),
+        gradients of sum(losses), tower average + clip to [-1, 1] by value (share_function.py:413-441),
+        RMSProp(1e-4) (:162-163), and after the FIRST step every trainable variable clipped to [-1, 1] (:690-691).
+        With torch.distributed initialised each rank is one tower: the batch is cut evenly (numpy.split, :654-656),
+        gradients are averaged with one all-reduce, loss and accuracy are tower means; every rank keeps its own
+        BatchNorm moving statistics (the reference's towers race on the shared ones).  Returns (loss, accuracy)."""
+        if self.optimizer_name != 'rmsprop':
+            raise NotImplementedError("DisCNN.train_step: only dis_optimizer 'rmsprop' is built")
+        x = np.ascontiguousarray(np.asarray(x).T, dtype=np.int32)            # tf.transpose, :260-262
+        xs = np.ascontiguousarray(np.asarray(xs).T, dtype=np.int32)
+        lab = np.ascontiguousarray(np.asarray(y, dtype=np.float32).T)
+        if x.ndim != 2 or x.shape[1] != self.max_len or xs.shape != x.shape or lab.shape != (x.shape[0], 2):
+            raise ValueError("train_step: x, xs [max_len=%d, B] and y [2, B] expected" % self.max_len)
+        world, rank = 1, 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+        if x.shape[0] % world != 0 or x.shape[0] < world:
+            raise ValueError("train_step: batch of %d cannot be split evenly over %d towers" % (x.shape[0], world))
+        per = x.shape[0] // world
+        x, xs, lab = x[rank * per:(rank + 1) * per], xs[rank * per:(rank + 1) * per], lab[rank * per:(rank + 1) * per]
+        tr = self._enable_training()
+        dev, M = self.device, x.shape[0]
+        xd, xsd = torch.from_numpy(x).to(dev), torch.from_numpy(xs).to(dev)
+        ld = torch.from_numpy(lab).to(dev)
+        need = lib.nmtgan_disc_train_workspace_bytes(C.byref(self._c), M)
+        if need == 0:
+            raise _lib.NmtGanError("disc train workspace: " + lib.nmtgan_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        st = _lib.stream_ptr()
+        check(lib.nmtgan_disc_train_grads(C.byref(self._c), C.byref(tr["pc"]), C.byref(tr["gc"]), ptr(xd), ptr(xsd), ptr(ld), M,
+                                          ptr(tr["loss"]), ptr(tr["acc"]), ptr(self._ws), self._ws.numel(), st),
+              "nmtgan_disc_train_grads")
+        la = torch.cat([tr["loss"], tr["acc"]])
+        if world > 1:
+            work_g, work_l = tr["grad"], la
+            if torch.distributed.get_backend() != "nccl":
+                work_g, work_l = tr["grad"].cpu(), la.cpu()
+            torch.distributed.all_reduce(work_g)
+            torch.distributed.all_reduce(work_l)
+            if work_g is not tr["grad"]:
+                tr["grad"].copy_(work_g)
+            la = work_l.to(dev) / world
+        grads = self._unpack(tr["grad"] / world) if return_grads else None
+        check(lib.nmtgan_rmsprop_update(ptr(tr["master"]), ptr(tr["ms"]), None, ptr(tr["grad"]), tr["n"], self.learning_rate,
+                                        0.9, 0.0, 1e-10, 1.0 / world, 1.0, ptr(tr["op"]), self._op, st), "nmtgan_rmsprop_update")
+        tr["steps"] += 1
+        if tr["steps"] == 1:
+            check(lib.nmtgan_clip_values(ptr(tr["master"]), tr["n"], -1.0, 1.0, ptr(tr["op"]), self._op, st),
+                  "nmtgan_clip_values")
+        self._fold_bn()
+        torch.cuda.synchronize(dev)
+        out = (float(la[0].item()), float(la[1].item()))
+        return out + (grads,) if return_grads else out
+
+    def _unpack(self, flat):
+        """Flat packed buffer -> {TF variable name: array in the variable's TF shape} (trainable variables)."""
+        tr, E, F, Fp = self._train, self.dim_word, self.num_filters_total, self.Fp
+        host = flat.cpu().numpy()
+        out = {}
+        col_off = np.concatenate([[0], np.cumsum(self.num_filters)]).astype(int)
+        for key, (tf_name, kind, o, n) in tr["index"].items():
+            a = host[o:o + n]
+            if kind == "tab":
+                out[tf_name] = a.reshape(-1, E).copy()
+            elif kind == "conv":
+                w = key[2]
+                nf = self.num_filters[self.filter_sizes.index(w)]
+                out[tf_name] = np.ascontiguousarray(a.reshape(nf, w * E).T).reshape(w, E, 1, nf)
+            elif kind == "vec":
+                for i, w in enumerate(self.filter_sizes):
+                    out[tf_name % w] = a[col_off[i]:col_off[i + 1]].copy()
+            elif kind == "hw":
+                out[tf_name] = np.ascontiguousarray(a.reshape(Fp, Fp)[:F, :F].T)
+            elif kind == "head":
+                h = a.reshape(2, 2 * Fp)
+                out[tf_name] = np.ascontiguousarray(np.concatenate([h[:, :F], h[:, Fp:Fp + F]], axis=1).T)
+            else:
+                out[tf_name] = a.copy()
+        return out
+
+    def get_weights(self) -> Dict[str, np.ndarray]:
+        """Every variable of the scope under its TF name and shape (what tf.train.Saver(params in scope) writes,
+        cnn_discriminator.py:202-205): trainable variables + BatchNorm moving statistics."""
+        if self._train is None:
+            return {k: np.asarray(self._W_src[k], np.float32) for k in self._all_names()}
+        out = self._unpack(self._train["master"])
+        col_off = np.concatenate([[0], np.cumsum(self.num_filters)]).astype(int)
+        for tkey, _, conv_fmt, _, _ in self._tf_names():
+            mm, mv = (t.cpu().numpy() for t in self._train["stats"][tkey])
+            for i, w in enumerate(self.filter_sizes):
+                bn = conv_fmt % w + "conv_batch_norm/bn/"
+                out[bn + "moving_mean"] = mm[col_off[i]:col_off[i + 1]].copy()
+                out[bn + "moving_variance"] = mv[col_off[i]:col_off[i + 1]].copy()
+        return out
+
+    def _all_names(self):
+        names = [self.scope + "/model_self/W", self.scope + "/model_self/b"]
+        for _, emb_name, conv_fmt, out_name, tr_name in self._tf_names():
+            names += [emb_name, out_name, tr_name]
+            for w in self.filter_sizes:
+                p = conv_fmt % w
+                names += [p + "self_model/W", p + "self_model/b"] + [p + "conv_batch_norm/bn/" + k for k in
+                                                                      ("gamma", "beta", "moving_mean", "moving_variance")]
+        return names
+
+    def save(self, prefix=None):
+        """saver.save(sess, saveto) (cnn_discriminator.py:699, gan_train.py:161): a TF V2 bundle of the scope."""
+        from . import tf_checkpoint
+        tf_checkpoint.save_checkpoint(str(self.saveto if prefix is None else prefix), self.get_weights(), update_state=False)
 
     @property
     def c_struct(self):
@@ -184,6 +411,8 @@ class DisCNN(object):
 
     # ------------------------------------------------------------------ out of scope
     def build_train_model(self, *a, **k):
-        raise NotImplementedError("discriminator training is outside the rollout-reward path (SURVEY section 8f-4)")
+        """Reference: cnn_discriminator.py:561-591 (graph construction; nothing to build here - see train_step)."""
 
-    train = build_train_model
+    def train(self, max_epoch=None, positive_data=None, negative_data=None, source_data=None):
+        raise NotImplementedError("DisCNN.train reads its batches with disThreeTextIterator / shuffle.py (data pipeline, out of "
+                                  "scope): feed each batch to train_step(x, y, xs) instead")

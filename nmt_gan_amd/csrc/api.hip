@@ -48,9 +48,16 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
              const int32_t* dec_in, const float* reward, int B, int Ls, int T, float* loss, float* p_target, void* ws,
              size_t ws_bytes, hipStream_t st);
 int rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay, float momentum,
-                   float eps, float grad_scale, void* w_op, int op_dtype, hipStream_t st);
+                   float eps, float grad_scale, float grad_clip, void* w_op, int op_dtype, hipStream_t st);
 int adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr, float rho,
                     float eps, float grad_scale, void* w_op, int op_dtype, hipStream_t st);
+int disc_train_workspace(const nmtgan_discriminator* d, int M, size_t* bytes);
+int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p, const nmtgan_disc_params* g, const int32_t* x,
+                     const int32_t* xs, const float* labels, int M, float* loss, float* accuracy, void* ws, size_t ws_bytes,
+                     hipStream_t st);
+int disc_fold_bn(const float* b, const float* gamma, const float* beta, const float* mean, const float* var, int n,
+                 float* scale, float* shift, hipStream_t st);
+int clip_values(float* w, int64_t n, float lo, float hi, void* w_op, int op_dtype, hipStream_t st);
 }  // namespace nmtgan
 
 using namespace nmtgan;
@@ -171,12 +178,31 @@ int nmtgan_pg_grads(const nmtgan_generator* g, const nmtgan_generator* grads, co
                   (hipStream_t)stream);
 }
 int nmtgan_rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay,
-                          float momentum, float eps, float grad_scale, void* w_op, int op_dtype, void* stream) {
-  return rmsprop_update(w, ms, mom, grad, n, lr, decay, momentum, eps, grad_scale, w_op, op_dtype, (hipStream_t)stream);
+                          float momentum, float eps, float grad_scale, float grad_clip, void* w_op, int op_dtype,
+                          void* stream) {
+  return rmsprop_update(w, ms, mom, grad, n, lr, decay, momentum, eps, grad_scale, grad_clip, w_op, op_dtype,
+                        (hipStream_t)stream);
 }
 int nmtgan_adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr, float rho,
                            float eps, float grad_scale, void* w_op, int op_dtype, void* stream) {
   return adadelta_update(w, accum, accum_update, grad, n, lr, rho, eps, grad_scale, w_op, op_dtype, (hipStream_t)stream);
+}
+size_t nmtgan_disc_train_workspace_bytes(const nmtgan_discriminator* d, int M) {
+  size_t b = 0;
+  if (!d) { set_error("disc_train_workspace: null discriminator"); return 0; }
+  return disc_train_workspace(d, M, &b) == 0 ? b : 0;
+}
+int nmtgan_disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p, const nmtgan_disc_params* grads,
+                            const int32_t* x, const int32_t* xs, const float* labels, int M, float* loss, float* accuracy,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  return disc_train_grads(d, p, grads, x, xs, labels, M, loss, accuracy, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int nmtgan_disc_fold_bn(const float* conv_b, const float* gamma, const float* beta, const float* moving_mean,
+                        const float* moving_var, int n, float* scale, float* shift, void* stream) {
+  return disc_fold_bn(conv_b, gamma, beta, moving_mean, moving_var, n, scale, shift, (hipStream_t)stream);
+}
+int nmtgan_clip_values(float* w, int64_t n, float lo, float hi, void* w_op, int op_dtype, void* stream) {
+  return clip_values(w, n, lo, hi, w_op, op_dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

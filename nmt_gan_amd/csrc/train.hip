@@ -24,14 +24,18 @@ static inline char* at(const void* base, int64_t elems, int es) { return (char*)
 
 // ------------------------------------------------------------------------------------------ small kernels
 // out[c][r] = in[r][c] for r < R, 0 for R <= r < Rp  (cast TI -> TO on the way)
+// group > 0: row r starts at (r / group) * group_stride + (r % group) * ld_in (the overlapping conv windows of a
+// sentence image, as in nmtgan_gemm_args.a_group), else at r * ld_in
 template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void transpose_cast_kernel(const TI* in, int64_t ld_in, int R, int C, TO* out, int Rp) {
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const TI* in, int64_t ld_in, int R, int C, TO* out, int Rp,
+                                                             int group, int64_t group_stride) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = 0; i < 16; ++i) {
     const int r = r0 + ty + 4 * i, c = c0 + tx;
-    tile[ty + 4 * i][tx] = (r < R && c < C) ? OpTraits<TI>::load(in + (int64_t)r * ld_in + c) : 0.f;
+    const int64_t off = group > 0 ? (int64_t)(r / group) * group_stride + (int64_t)(r % group) * ld_in : (int64_t)r * ld_in;
+    tile[ty + 4 * i][tx] = (r < R && c < C) ? OpTraits<TI>::load(in + off + c) : 0.f;
   }
   __syncthreads();
   for (int i = 0; i < 16; ++i) {
@@ -40,20 +44,22 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const TI* in, int64
   }
 }
 template <typename TI, typename TO>
-static int transpose_t(const void* in, int64_t ld_in, int R, int C, void* out, int Rp, hipStream_t st) {
+static int transpose_t(const void* in, int64_t ld_in, int R, int C, void* out, int Rp, int group, int64_t group_stride,
+                       hipStream_t st) {
   dim3 grid((Rp + 63) / 64, (C + 63) / 64), block(256);
-  hipLaunchKernelGGL((transpose_cast_kernel<TI, TO>), grid, block, 0, st, (const TI*)in, ld_in, R, C, (TO*)out, Rp);
+  hipLaunchKernelGGL((transpose_cast_kernel<TI, TO>), grid, block, 0, st, (const TI*)in, ld_in, R, C, (TO*)out, Rp, group,
+                     group_stride);
   NMTGAN_CHECK_LAUNCH("transpose_cast");
   return 0;
 }
 // in_f32 != 0: input is fp32, else op dtype; output always op dtype
 static int launch_transpose(int op, int in_f32, const void* in, int64_t ld_in, int R, int C, void* out, int Rp,
-                            hipStream_t st) {
+                            hipStream_t st, int group = 0, int64_t group_stride = 0) {
   prof::Scope prof_scope(prof::OTHER, st);
   NMTGAN_REQUIRE(in && out && R > 0 && C > 0 && Rp >= R, "transpose: bad arguments");
-  if (op == NMTGAN_F32) return transpose_t<float, float>(in, ld_in, R, C, out, Rp, st);
-  return in_f32 ? transpose_t<float, bf16_t>(in, ld_in, R, C, out, Rp, st)
-                : transpose_t<bf16_t, bf16_t>(in, ld_in, R, C, out, Rp, st);
+  if (op == NMTGAN_F32) return transpose_t<float, float>(in, ld_in, R, C, out, Rp, group, group_stride, st);
+  return in_f32 ? transpose_t<float, bf16_t>(in, ld_in, R, C, out, Rp, group, group_stride, st)
+                : transpose_t<bf16_t, bf16_t>(in, ld_in, R, C, out, Rp, group, group_stride, st);
 }
 
 // out[c] = sum_r in[r][c] in a fixed order: grid.y row chunks of `rows_per_chunk` rows (4 row lanes per column,
@@ -347,10 +353,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* dx, const i
 // g = grad * grad_scale (tower average, model.py:689-722); w_op (optional) = the refreshed MFMA-operand copy.
 template <typename OpT>
 __global__ void rmsprop_kernel(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay,
-                               float momentum, float eps, float grad_scale, OpT* w_op) {
+                               float momentum, float eps, float grad_scale, float grad_clip, OpT* w_op) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float g = grad[i] * grad_scale;
+  float g = grad[i] * grad_scale;
+  if (grad_clip > 0.f) g = fminf(fmaxf(g, -grad_clip), grad_clip);
   const float m = ms[i] + (g * g - ms[i]) * (1.0f - decay);
   ms[i] = m;
   float step = lr * g / sqrtf(m + eps);
@@ -361,7 +368,7 @@ __global__ void rmsprop_kernel(float* w, float* ms, float* mom, const float* gra
 }
 
 int rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay, float momentum,
-                   float eps, float grad_scale, void* w_op, int op_dtype, hipStream_t st) {
+                   float eps, float grad_scale, float grad_clip, void* w_op, int op_dtype, hipStream_t st) {
   prof::Scope prof_scope(prof::OTHER, st);
   if (n == 0) return 0;
   NMTGAN_REQUIRE(w && ms && grad && n > 0, "rmsprop_update: null pointer");
@@ -369,10 +376,10 @@ int rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n
   dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (w_op && op_dtype == NMTGAN_BF16)
     hipLaunchKernelGGL(rmsprop_kernel<bf16_t>, grid, block, 0, st, w, ms, mom, grad, n, lr, decay, momentum, eps, grad_scale,
-                       (bf16_t*)w_op);
+                       grad_clip, (bf16_t*)w_op);
   else
     hipLaunchKernelGGL(rmsprop_kernel<float>, grid, block, 0, st, w, ms, mom, grad, n, lr, decay, momentum, eps, grad_scale,
-                       (float*)(op_dtype == NMTGAN_F32 ? w_op : nullptr));
+                       grad_clip, (float*)(op_dtype == NMTGAN_F32 ? w_op : nullptr));
   NMTGAN_CHECK_LAUNCH("rmsprop");
   return 0;
 }
@@ -433,30 +440,54 @@ static int dense_seg(int op, const void* A, int64_t lda, int M, int K, int N, co
   return launch_gemm(&a, st);
 }
 
+// out[r][c] = in[r][c] for c < C, 0 for C <= c < Cp (op dtype): gives a GEMM operand whose row length meets the
+// 16-byte rule when C does not (discriminator filter counts 100 + 10 w)
+template <typename OpT>
+__global__ void cast_pad_kernel(const float* in, int R, int C, int Cp, OpT* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)R * Cp) return;
+  const int c = (int)(i % Cp);
+  const int64_t r = i / Cp;
+  OpTraits<OpT>::store(out + i, c < C ? in[r * C + c] : 0.f);
+}
+static int launch_cast_pad(int op, const float* in, int R, int C, int Cp, void* out, hipStream_t st) {
+  prof::Scope prof_scope(prof::OTHER, st);
+  const int64_t n = (int64_t)R * Cp;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (op == NMTGAN_BF16) hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, grid, block, 0, st, in, R, C, Cp, (bf16_t*)out);
+  else hipLaunchKernelGGL(cast_pad_kernel<float>, grid, block, 0, st, in, R, C, Cp, (float*)out);
+  NMTGAN_CHECK_LAUNCH("cast_pad");
+  return 0;
+}
+
 struct BwdScratch { void* dYo; void* dYT; void* XT; void* WT; float* colsum; };
 
 // Backward of Y = X . W + b with Wt[N][K] packed: gw.w <- dWt [N][K] fp32, gw.b <- colsum(dY), dX (optional) [M][K].
 // dY is fp32 [M][N] (dY_op == nullptr) or already in op dtype (dY_f32 == nullptr; no bias then).
 static int dense_bwd(int op, const float* dY_f32, const void* dY_op, int M, int N, int K, const void* X, int x_f32,
-                     const nmtgan_dense& w, const nmtgan_dense& gw, float* dX, const BwdScratch& s, hipStream_t st) {
+                     const nmtgan_dense& w, const nmtgan_dense& gw, float* dX, const BwdScratch& s, hipStream_t st,
+                     int64_t x_ld = 0, int x_group = 0, int64_t x_group_stride = 0) {
   const int Mp = (M + 63) / 64 * 64;
   if (gw.b) {
     NMTGAN_REQUIRE(dY_f32 != nullptr, "dense_bwd: bias gradient needs the fp32 dY");
     NMTGAN_TRY(launch_colsum(dY_f32, N, M, N, (float*)gw.b, s.colsum, st));
   }
+  const int Np = (N + 7) / 8 * 8;                 // operand row length of the dX product (16-byte rule)
   const void* dYo = dY_op;
   if (dY_f32) {
     NMTGAN_TRY(launch_transpose(op, 1, dY_f32, N, M, N, s.dYT, Mp, st));
-    if (op == NMTGAN_F32) dYo = dY_f32;
+    if (dX && Np != N) { NMTGAN_TRY(launch_cast_pad(op, dY_f32, M, N, Np, s.dYo, st)); dYo = s.dYo; }
+    else if (op == NMTGAN_F32) dYo = dY_f32;
     else if (dX) { NMTGAN_TRY(launch_cast_rows(dY_f32, s.dYo, op, (int64_t)M * N, st)); dYo = s.dYo; }
   } else {
+    NMTGAN_REQUIRE(Np == N || !dX, "dense_bwd: op-dtype dY needs N %% 8 == 0");
     NMTGAN_TRY(launch_transpose(op, 0, dY_op, N, M, N, s.dYT, Mp, st));
   }
-  NMTGAN_TRY(launch_transpose(op, x_f32, X, K, M, K, s.XT, Mp, st));
+  NMTGAN_TRY(launch_transpose(op, x_f32, X, x_ld > 0 ? x_ld : K, M, K, s.XT, Mp, st, x_group, x_group_stride));
   NMTGAN_TRY(gemm_f32out(op, s.dYT, Mp, N, Mp, K, s.XT, nullptr, (float*)gw.w, K, st));          // dWt = dY^T . X
   if (dX) {
-    NMTGAN_TRY(launch_transpose(op, 0, w.w, K, N, K, s.WT, N, st));                               // W^T as [K][N]
-    NMTGAN_TRY(gemm_f32out(op, dYo, N, M, N, K, s.WT, nullptr, dX, K, st));                       // dX = dY . W
+    NMTGAN_TRY(launch_transpose(op, 0, w.w, K, N, K, s.WT, Np, st));                              // W^T as [K][Np]
+    NMTGAN_TRY(gemm_f32out(op, dYo, Np, M, Np, K, s.WT, nullptr, dX, K, st));                     // dX = dY . W
   }
   return 0;
 }
@@ -730,6 +761,409 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
     NMTGAN_CHECK_LAUNCH("embed_bwd");
   }
   (void)es;
+  return 0;
+}
+
+
+// ==========================================================================================================
+// Discriminator training step: one iteration of DisCNN.train (cnn_discriminator.py:664-691)
+// = build_model (248-345) in training mode for one tower + the gradients of sum(losses).
+//   forward  embed -> per width: conv + bias (MFMA GEMM over the overlapping windows, raw fp32) -> BatchNorm with
+//            BATCH moments over (sentence, window) per filter -> ReLU -> max over time (+ argmax) -> highway ->
+//            [target | source] . W + b -> softmax cross-entropy; moving statistics moved in place (decay 0.9)
+//   backward head -> highway -> per width: max/ReLU/BatchNorm backward (dense: the batch moments couple every window)
+//            -> conv weights (dc^T . im2col, transposed copies) and sentence image (dc . W^T, overlap-add) -> tables
+// ==========================================================================================================
+
+// out[c] = scale * sum_r (in[r][c] - (center ? center[c] : 0))^2, two-level like colsum_kernel
+__global__ __launch_bounds__(256) void colsumsq_kernel(const float* in, int64_t ld, int R, int C, int rows_per_chunk,
+                                                       const float* center, float* out) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (c < C) {
+    const float mu = center ? center[c] : 0.f;
+    for (int r = r0 + ty; r < r1; r += 4) { const float v = in[(int64_t)r * ld + c] - mu; s += v * v; }
+  }
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) out[(int64_t)blockIdx.y * C + c] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+}
+__global__ void scale_kernel(float* v, int n, float a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] *= a;
+}
+// batch mean / biased variance per column of raw[R][C] (tf.nn.moments); scratch: 2 * COLSUM_CHUNKS * C floats
+static int launch_col_moments(const float* raw, int R, int C, float* mean, float* var, float* scratch, hipStream_t st) {
+  NMTGAN_TRY(launch_colsum(raw, C, R, C, mean, scratch, st));
+  prof::Scope prof_scope(prof::OTHER, st);
+  hipLaunchKernelGGL(scale_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, C, 1.0f / (float)R);
+  int chunks = std::min(COLSUM_CHUNKS, (R + 63) / 64);
+  const int per = (R + chunks - 1) / chunks;
+  chunks = (R + per - 1) / per;
+  hipLaunchKernelGGL(colsumsq_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, raw, (int64_t)C, R, C, per, mean,
+                     chunks > 1 ? scratch : var);
+  if (chunks > 1) hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, chunks, C, var);
+  hipLaunchKernelGGL(scale_kernel, dim3((C + 255) / 256), dim3(256), 0, st, var, C, 1.0f / (float)R);
+  NMTGAN_CHECK_LAUNCH("col_moments");
+  return 0;
+}
+
+// pooled[m][f] = max_p relu((raw[m*P+p][f] - mean) * rstd * gamma + beta), arg[m][f] = first p reaching it
+// (contrib batch_norm is_training=True eps 1e-3, relu, max_pool; cnn_discriminator.py:22-33, 105, 282-283);
+// also moves the moving statistics (updates_collections=None): moving = moving*decay + batch*(1-decay)
+__global__ void bn_relu_max_kernel(const float* raw, const float* mean, const float* var, const float* gamma,
+                                   const float* beta, int M, int P, int n, float* pooled, int64_t ld_pool, int32_t* arg,
+                                   int64_t ld_arg, float* moving_mean, float* moving_var, float decay) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = blockIdx.y;
+  if (f >= n) return;
+  const float mu = mean[f], rs = rsqrtf(var[f] + 1e-3f), g = gamma[f], b = beta[f];
+  float best = 0.f;
+  int bi = 0;
+  for (int p = 0; p < P; ++p) {
+    const float v = fmaxf((raw[((int64_t)m * P + p) * n + f] - mu) * rs * g + b, 0.f);
+    if (v > best) { best = v; bi = p; }
+  }
+  pooled[(int64_t)m * ld_pool + f] = best;
+  arg[(int64_t)m * ld_arg + f] = bi;
+  if (m == 0 && moving_mean) {
+    moving_mean[f] = moving_mean[f] * decay + mu * (1.0f - decay);
+    moving_var[f] = moving_var[f] * decay + var[f] * (1.0f - decay);
+  }
+}
+
+// per filter: dbeta = sum_m dn, dgamma = sum_m dn * xhat at the arg-max window, dn = dH[m][f] where the pooled
+// value is positive (ReLU active), fixed order over m
+__global__ void bn_bwd_stats_kernel(const float* dH, int64_t ld_dh, const float* pooled, int64_t ld_pool, const int32_t* arg,
+                                    int64_t ld_arg, const float* raw, const float* mean, const float* var, int M, int P, int n,
+                                    float* dgamma, float* dbeta) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const float mu = mean[f], rs = rsqrtf(var[f] + 1e-3f);
+  float dg = 0.f, db = 0.f;
+  for (int m = 0; m < M; ++m) {
+    if (!(pooled[(int64_t)m * ld_pool + f] > 0.f)) continue;
+    const float d = dH[(int64_t)m * ld_dh + f];
+    const int p = arg[(int64_t)m * ld_arg + f];
+    dg += d * (raw[((int64_t)m * P + p) * n + f] - mu) * rs;
+    db += d;
+  }
+  dgamma[f] = dg;
+  dbeta[f] = db;
+}
+// dc[r][f] = gamma * rstd / R * (R * dn[r][f] - dbeta - xhat[r][f] * dgamma)
+__global__ void bn_bwd_dense_kernel(const float* dH, int64_t ld_dh, const float* pooled, int64_t ld_pool, const int32_t* arg,
+                                    int64_t ld_arg, const float* raw, const float* mean, const float* var, const float* gamma,
+                                    const float* dgamma, const float* dbeta, int M, int P, int n, float* dc) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (f >= n) return;
+  const int m = r / P, p = r % P;
+  const float mu = mean[f], rs = rsqrtf(var[f] + 1e-3f);
+  const float R = (float)M * (float)P;
+  float dn = 0.f;
+  if (pooled[(int64_t)m * ld_pool + f] > 0.f && arg[(int64_t)m * ld_arg + f] == p) dn = dH[(int64_t)m * ld_dh + f];
+  const float xh = (raw[(int64_t)r * n + f] - mu) * rs;
+  dc[(int64_t)r * n + f] = gamma[f] * rs / R * (R * dn - dbeta[f] - xh * dgamma[f]);
+}
+
+// de[m][t][c] += sum_j dcol[(m, t-j)][j*E + c] over the windows p = t - j in [0, P) that cover token t
+__global__ void col2im_add_kernel(const float* dcol, int M, int T, int E, int w, int P, float* de) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * T * E) return;
+  const int c = (int)(i % E), t = (int)((i / E) % T), m = (int)(i / ((int64_t)E * T));
+  float s = 0.f;
+  for (int j = 0; j < w; ++j) {
+    const int p = t - j;
+    if (p >= 0 && p < P) s += dcol[((int64_t)m * P + p) * ((int64_t)w * E) + (int64_t)j * E + c];
+  }
+  de[i] += s;
+}
+
+// highway backward (cnn_discriminator.py:50-59): out = t*o + (1-t)*H, o = relu(o_pre), t = sigmoid(t_pre)
+__global__ void highway_bwd_kernel(const float* dout, const float* H, const float* o_pre, const float* t_pre, int64_t n,
+                                   float* d_o_pre, float* d_t_pre, float* dH) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float t = 1.f / (1.f + expf(-t_pre[i])), o = fmaxf(o_pre[i], 0.f), d = dout[i];
+  d_o_pre[i] = o_pre[i] > 0.f ? d * t : 0.f;
+  d_t_pre[i] = d * (o - H[i]) * t * (1.f - t);
+  dH[i] = d * (1.f - t);
+}
+
+// scores = [ft | fs] . W + b, softmax cross-entropy against labels[m][2] (cnn_discriminator.py:318-326):
+// loss_row = -sum_c y_c log p_c, ds_c = p_c * sum(y) - y_c (gradient of the SUM of the losses), correct = argmax match
+__global__ __launch_bounds__(256) void disc_head_train_kernel(const float* ft, const float* fs, int M, int Fp, const float* head_w,
+                                                              const float* head_b, const float* labels, float* ds,
+                                                              float* loss_row, float* correct) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int k = lane; k < Fp; k += 64) {
+    const float a = ft[(int64_t)r * Fp + k], b = fs[(int64_t)r * Fp + k];
+    s0 += a * head_w[k] + b * head_w[Fp + k];
+    s1 += a * head_w[2 * Fp + k] + b * head_w[3 * Fp + k];
+  }
+  s0 = wave_sum(s0) + head_b[0];
+  s1 = wave_sum(s1) + head_b[1];
+  if (lane == 0) {
+    const float mx = fmaxf(s0, s1), lse = mx + logf(expf(s0 - mx) + expf(s1 - mx));
+    const float y0 = labels[2 * r], y1 = labels[2 * r + 1];
+    const float p0 = expf(s0 - lse), p1 = expf(s1 - lse);
+    loss_row[r] = -(y0 * (s0 - lse) + y1 * (s1 - lse));
+    ds[2 * r] = p0 * (y0 + y1) - y0;
+    ds[2 * r + 1] = p1 * (y0 + y1) - y1;
+    correct[r] = ((s1 > s0) == (y1 > y0)) ? 1.f : 0.f;            // tf.argmax: first index on ties
+  }
+}
+// dW[c][k] = sum_m ds[m][c] * featcat[m][k] (fixed order), dfeat[m][k] = sum_c ds[m][c] * W[c][k]; k in [0, 2Fp)
+__global__ void disc_head_bwd_kernel(const float* ft, const float* fs, const float* ds, const float* head_w, int M, int Fp,
+                                     float* dW, float* dft, float* dfs) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= 2 * Fp) return;
+  const float* feat = k < Fp ? ft + k : fs + (k - Fp);
+  float* dfeat = k < Fp ? dft + k : dfs + (k - Fp);
+  const float w0 = head_w[k], w1 = head_w[2 * Fp + k];
+  float a0 = 0.f, a1 = 0.f;
+  for (int m = 0; m < M; ++m) {
+    const float v = feat[(int64_t)m * Fp], d0 = ds[2 * m], d1 = ds[2 * m + 1];
+    a0 += d0 * v;
+    a1 += d1 * v;
+    dfeat[(int64_t)m * Fp] = d0 * w0 + d1 * w1;
+  }
+  dW[k] = a0;
+  dW[2 * Fp + k] = a1;
+}
+// db[c] = sum_m ds[m][c]; loss = mean(loss_row); accuracy = mean(correct)   (one workgroup, fixed order)
+__global__ __launch_bounds__(64) void disc_head_reduce_kernel(const float* ds, const float* loss_row, const float* correct, int M,
+                                                              float* db, float* loss, float* acc) {
+  if (threadIdx.x != 0) return;
+  double b0 = 0, b1 = 0, l = 0, a = 0;
+  for (int m = 0; m < M; ++m) { b0 += ds[2 * m]; b1 += ds[2 * m + 1]; l += loss_row[m]; a += correct[m]; }
+  db[0] = (float)b0; db[1] = (float)b1;
+  loss[0] = (float)(l / M);
+  acc[0] = (float)(a / M);
+}
+
+// inference constants of a tower from its trainable + moving statistics (what DisCNN.load_weights folds on the host):
+// scale = gamma * rsqrt(var + 1e-3), shift = (b - mean) * scale + beta
+__global__ void bn_fold_kernel(const float* b, const float* gamma, const float* beta, const float* mean, const float* var,
+                               int n, float* scale, float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sc = gamma[i] * rsqrtf(var[i] + 1e-3f);
+  scale[i] = sc;
+  shift[i] = (b[i] - mean[i]) * sc + beta[i];
+}
+int disc_fold_bn(const float* b, const float* gamma, const float* beta, const float* mean, const float* var, int n,
+                 float* scale, float* shift, hipStream_t st) {
+  prof::Scope prof_scope(prof::OTHER, st);
+  NMTGAN_REQUIRE(b && gamma && beta && mean && var && scale && shift && n > 0, "disc_fold_bn: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b, gamma, beta, mean, var, n, scale, shift);
+  NMTGAN_CHECK_LAUNCH("bn_fold");
+  return 0;
+}
+// w = clamp(w, lo, hi) (+ refreshed operand copy): the one-off clip_ops of DisCNN.train (cnn_discriminator.py:583-591, 690)
+template <typename OpT>
+__global__ void clip_values_kernel(float* w, int64_t n, float lo, float hi, OpT* w_op) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = fminf(fmaxf(w[i], lo), hi);
+  w[i] = v;
+  if (w_op) OpTraits<OpT>::store(w_op + i, v);
+}
+int clip_values(float* w, int64_t n, float lo, float hi, void* w_op, int op_dtype, hipStream_t st) {
+  prof::Scope prof_scope(prof::OTHER, st);
+  if (n == 0) return 0;
+  NMTGAN_REQUIRE(w && n > 0 && lo <= hi, "clip_values: bad arguments");
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (w_op && op_dtype == NMTGAN_BF16) hipLaunchKernelGGL(clip_values_kernel<bf16_t>, grid, block, 0, st, w, n, lo, hi, (bf16_t*)w_op);
+  else hipLaunchKernelGGL(clip_values_kernel<float>, grid, block, 0, st, w, n, lo, hi, (float*)(op_dtype == NMTGAN_F32 ? w_op : nullptr));
+  NMTGAN_CHECK_LAUNCH("clip_values");
+  return 0;
+}
+
+struct DtBufs {
+  void* e[2]; float* raw[2]; float* mean[2]; float* var[2]; float* pooled[2]; int32_t* arg[2]; void* pooled_op;
+  float* o_pre[2]; float* t_pre[2]; float* feat[2];
+  float *ds, *loss_row, *correct, *dfeat[2], *d_o, *d_t, *dH, *dtmp, *dgb, *dc, *dcol, *de;
+  BwdScratch s;
+};
+static int64_t raw_elems(const nmtgan_discriminator* d, int M) {
+  int64_t n = 0;
+  for (int i = 0; i < d->n_widths; ++i) n += (int64_t)M * (d->max_len - d->widths[i] + 1) * d->n_filters[i];
+  return n;
+}
+static void carve_dt(Arena& ar, const nmtgan_discriminator* d, int M, DtBufs& b) {
+  const int T = d->max_len, E = d->dim_word, Fp = d->Fp, es = dtype_size(d->op_dtype);
+  int64_t max_rn = 0, max_rk = 0, max_kn = 0, max_n = 0, max_k = 0, max_rp = 0;
+  for (int i = 0; i < d->n_widths; ++i) {
+    const int64_t R = (int64_t)M * (T - d->widths[i] + 1), Rp = (R + 63) / 64 * 64, n = d->n_filters[i], k = (int64_t)d->widths[i] * E;
+    const int64_t np8 = (n + 7) / 8 * 8;
+    max_rn = std::max(max_rn, R * np8); max_rk = std::max(max_rk, Rp * k); max_kn = std::max(max_kn, k * np8);
+    max_n = std::max(max_n, n); max_k = std::max(max_k, k); max_rp = std::max(max_rp, Rp * n);
+  }
+  const int64_t Mp = (M + 63) / 64 * 64;
+  for (int t = 0; t < 2; ++t) {
+    b.e[t] = ar.take((int64_t)M * T * E * es);
+    b.raw[t] = ar.get<float>(raw_elems(d, M));
+    b.mean[t] = ar.get<float>(Fp); b.var[t] = ar.get<float>(Fp);
+    b.pooled[t] = ar.get<float>((int64_t)M * Fp); b.arg[t] = ar.get<int32_t>((int64_t)M * Fp);
+    b.o_pre[t] = ar.get<float>((int64_t)M * Fp); b.t_pre[t] = ar.get<float>((int64_t)M * Fp);
+    b.feat[t] = ar.get<float>((int64_t)M * Fp); b.dfeat[t] = ar.get<float>((int64_t)M * Fp);
+  }
+  b.pooled_op = ar.take((int64_t)M * Fp * es);
+  b.ds = ar.get<float>(2 * M); b.loss_row = ar.get<float>(M); b.correct = ar.get<float>(M);
+  b.d_o = ar.get<float>((int64_t)M * Fp); b.d_t = ar.get<float>((int64_t)M * Fp); b.dH = ar.get<float>((int64_t)M * Fp);
+  b.dtmp = ar.get<float>((int64_t)M * Fp); b.dgb = ar.get<float>(2 * Fp);
+  b.dc = ar.get<float>(max_rn); b.dcol = ar.get<float>(max_rk); b.de = ar.get<float>((int64_t)M * T * E);
+  b.s.dYo = ar.take(std::max(max_rn, (int64_t)M * Fp) * es);
+  b.s.dYT = ar.take(std::max(max_rp, (int64_t)Fp * Mp) * es);
+  b.s.XT = ar.take(std::max(max_rk, (int64_t)Fp * Mp) * es);
+  b.s.WT = ar.take(std::max(max_kn, (int64_t)Fp * Fp) * es);
+  b.s.colsum = ar.get<float>((int64_t)2 * COLSUM_CHUNKS * std::max<int64_t>(max_n, Fp));
+}
+static int check_dt(const nmtgan_discriminator* d, const nmtgan_disc_params* p, const nmtgan_disc_params* g, int M) {
+  NMTGAN_REQUIRE(d && p && g, "disc_train: null argument");
+  NMTGAN_REQUIRE(d->op_dtype == NMTGAN_BF16 || d->op_dtype == NMTGAN_F32, "disc_train: bad op_dtype");
+  NMTGAN_REQUIRE(d->n_widths > 0 && d->n_widths <= NMTGAN_MAX_WIDTHS && d->max_len > 0 && d->dim_word > 0 && d->dim_word % 8 == 0,
+                 "disc_train: bad geometry (dim_word must be a multiple of 8)");
+  NMTGAN_REQUIRE(d->Fp % 64 == 0 && d->F <= d->Fp && M > 0, "disc_train: bad F/Fp/M");
+  int F = 0;
+  for (int i = 0; i < d->n_widths; ++i) {
+    NMTGAN_REQUIRE(d->widths[i] >= 1 && d->widths[i] <= d->max_len && d->n_filters[i] > 0,
+                   "disc_train: width %d / %d filters", d->widths[i], d->n_filters[i]);
+    F += d->n_filters[i];
+  }
+  NMTGAN_REQUIRE(F == d->F, "disc_train: F does not match the filter counts");
+  return 0;
+}
+int disc_train_workspace(const nmtgan_discriminator* d, int M, size_t* bytes) {
+  nmtgan_disc_params dummy{};
+  NMTGAN_TRY(check_dt(d, &dummy, &dummy, M));
+  Arena ar(nullptr, 0);
+  DtBufs b;
+  carve_dt(ar, d, M, b);
+  *bytes = align_up(ar.off, 256) + 256;
+  return 0;
+}
+
+int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p, const nmtgan_disc_params* g, const int32_t* x,
+                     const int32_t* xs, const float* labels, int M, float* loss, float* accuracy, void* ws, size_t ws_bytes,
+                     hipStream_t st) {
+  NMTGAN_TRY(check_dt(d, p, g, M));
+  NMTGAN_REQUIRE(x && xs && labels && loss && accuracy && ws, "disc_train: null pointer");
+  Arena ar(ws, ws_bytes);
+  DtBufs b;
+  carve_dt(ar, d, M, b);
+  NMTGAN_REQUIRE(!ar.overflow, "disc_train: workspace too small (%zu bytes given)", ws_bytes);
+  const int T = d->max_len, E = d->dim_word, Fp = d->Fp, F = d->F, op = d->op_dtype, es = dtype_size(op);
+  const nmtgan_disc_tower* tws[2] = {&d->tgt, &d->src};
+  const nmtgan_disc_tower_params* tps[2] = {&p->tgt, &p->src};
+  const nmtgan_disc_tower_params* tgs[2] = {&g->tgt, &g->src};
+  const int32_t* ids[2] = {x, xs};
+  // ---------------- forward
+  for (int t = 0; t < 2; ++t) {
+    const nmtgan_disc_tower& tw = *tws[t];
+    const nmtgan_disc_tower_params& tp = *tps[t];
+    NMTGAN_REQUIRE(tp.conv_b && tp.gamma && tp.beta && tp.moving_mean && tp.moving_var, "disc_train: null tower parameter");
+    NMTGAN_TRY(launch_disc_embed(tw.emb, op, t ? d->vocab_s : d->vocab, ids[t], (int64_t)M * T, E, b.e[t], st));
+    NMTGAN_REQUIRE(hipMemsetAsync(b.pooled[t], 0, (size_t)M * Fp * sizeof(float), st) == hipSuccess &&
+                   hipMemsetAsync(b.arg[t], 0, (size_t)M * Fp * sizeof(int32_t), st) == hipSuccess, "disc_train: memset failed");
+    int col = 0;
+    float* raw = b.raw[t];
+    for (int i = 0; i < d->n_widths; ++i) {
+      const int w = d->widths[i], P = T - w + 1, n = d->n_filters[i], R = M * P;
+      nmtgan_gemm_args a{};
+      a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
+      a.A = b.e[t]; a.Wt = tw.conv_w[i]; a.M = R; a.N = n; a.K = w * E;
+      a.lda = E; a.a_group = P; a.a_group_stride = (int64_t)T * E;
+      a.bias = tp.conv_b + col; a.n_seg = 1; a.seg_width = n; a.out[0] = raw; a.ldo[0] = n; a.out_f32[0] = 1; a.seg_scale[0] = 1.f;
+      NMTGAN_TRY(launch_gemm(&a, st));
+      NMTGAN_TRY(launch_col_moments(raw, R, n, b.mean[t] + col, b.var[t] + col, b.s.colsum, st));
+      {
+        prof::Scope prof_scope(prof::OTHER, st);
+        hipLaunchKernelGGL(bn_relu_max_kernel, dim3((n + 63) / 64, M), dim3(64), 0, st, raw, b.mean[t] + col, b.var[t] + col,
+                           tp.gamma + col, tp.beta + col, M, P, n, b.pooled[t] + col, (int64_t)Fp, b.arg[t] + col, (int64_t)Fp,
+                           tp.moving_mean + col, tp.moving_var + col, 0.9f);
+        NMTGAN_CHECK_LAUNCH("bn_relu_max");
+      }
+      raw += (int64_t)R * n;
+      col += n;
+    }
+    NMTGAN_TRY(launch_cast_rows(b.pooled[t], b.pooled_op, op, (int64_t)M * Fp, st));
+    NMTGAN_TRY(gemm_f32out(op, b.pooled_op, Fp, M, Fp, Fp, tw.hw_out, nullptr, b.o_pre[t], Fp, st));
+    NMTGAN_TRY(gemm_f32out(op, b.pooled_op, Fp, M, Fp, Fp, tw.hw_tr, nullptr, b.t_pre[t], Fp, st));
+    NMTGAN_TRY(launch_highway_gate(b.pooled[t], b.o_pre[t], b.t_pre[t], b.feat[t], (int64_t)M * Fp, st));
+  }
+  {
+    prof::Scope prof_scope(prof::OTHER, st);
+    hipLaunchKernelGGL(disc_head_train_kernel, dim3((M + 3) / 4), dim3(256), 0, st, b.feat[0], b.feat[1], M, Fp, d->head_w,
+                       d->head_b, labels, b.ds, b.loss_row, b.correct);
+    hipLaunchKernelGGL(disc_head_reduce_kernel, dim3(1), dim3(64), 0, st, b.ds, b.loss_row, b.correct, M, g->head_b, loss,
+                       accuracy);
+    hipLaunchKernelGGL(disc_head_bwd_kernel, dim3((2 * Fp + 255) / 256), dim3(256), 0, st, b.feat[0], b.feat[1], b.ds,
+                       d->head_w, M, Fp, g->head_w, b.dfeat[0], b.dfeat[1]);
+    NMTGAN_CHECK_LAUNCH("disc_head_train");
+  }
+  // ---------------- backward, tower by tower
+  for (int t = 0; t < 2; ++t) {
+    const nmtgan_disc_tower& tw = *tws[t];
+    const nmtgan_disc_tower_params& tp = *tps[t];
+    const nmtgan_disc_tower_params& tg = *tgs[t];
+    NMTGAN_REQUIRE(tg.emb && tg.conv_b && tg.gamma && tg.beta && tg.hw_out && tg.hw_tr, "disc_train: null gradient buffer");
+    {
+      prof::Scope prof_scope(prof::OTHER, st);
+      const int64_t n = (int64_t)M * Fp;
+      hipLaunchKernelGGL(highway_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b.dfeat[t], b.pooled[t],
+                         b.o_pre[t], b.t_pre[t], n, b.d_o, b.d_t, b.dH);
+      NMTGAN_CHECK_LAUNCH("highway_bwd");
+    }
+    nmtgan_dense wo{tw.hw_out, nullptr}, wt{tw.hw_tr, nullptr}, go{tg.hw_out, nullptr}, gt{tg.hw_tr, nullptr};
+    NMTGAN_TRY(dense_bwd(op, b.d_o, nullptr, M, Fp, Fp, b.pooled[t], 1, wo, go, b.dtmp, b.s, st));
+    NMTGAN_TRY(launch_add_inplace(b.dH, b.dtmp, (int64_t)M * Fp, st));
+    NMTGAN_TRY(dense_bwd(op, b.d_t, nullptr, M, Fp, Fp, b.pooled[t], 1, wt, gt, b.dtmp, b.s, st));
+    NMTGAN_TRY(launch_add_inplace(b.dH, b.dtmp, (int64_t)M * Fp, st));
+    NMTGAN_REQUIRE(hipMemsetAsync(b.de, 0, (size_t)M * T * E * sizeof(float), st) == hipSuccess, "disc_train: memset failed");
+    int col = 0;
+    const float* raw = b.raw[t];
+    for (int i = 0; i < d->n_widths; ++i) {
+      const int w = d->widths[i], P = T - w + 1, n = d->n_filters[i], R = M * P, K = w * E;
+      NMTGAN_REQUIRE(tg.conv_w[i] != nullptr, "disc_train: null conv gradient buffer");
+      {
+        prof::Scope prof_scope(prof::OTHER, st);
+        hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((n + 63) / 64), dim3(64), 0, st, b.dH + col, (int64_t)Fp, b.pooled[t] + col,
+                           (int64_t)Fp, b.arg[t] + col, (int64_t)Fp, raw, b.mean[t] + col, b.var[t] + col, M, P, n,
+                           tg.gamma + col, tg.beta + col);
+        hipLaunchKernelGGL(bn_bwd_dense_kernel, dim3((n + 63) / 64, R), dim3(64), 0, st, b.dH + col, (int64_t)Fp,
+                           b.pooled[t] + col, (int64_t)Fp, b.arg[t] + col, (int64_t)Fp, raw, b.mean[t] + col, b.var[t] + col,
+                           tp.gamma + col, tg.gamma + col, tg.beta + col, M, P, n, b.dc);
+        NMTGAN_CHECK_LAUNCH("bn_bwd");
+      }
+      nmtgan_dense cw{tw.conv_w[i], nullptr}, cg{tg.conv_w[i], tg.conv_b + col};
+      NMTGAN_TRY(dense_bwd(op, b.dc, nullptr, R, n, K, b.e[t], 0, cw, cg, b.dcol, b.s, st, E, P, (int64_t)T * E));
+      {
+        prof::Scope prof_scope(prof::OTHER, st);
+        const int64_t tot = (int64_t)M * T * E;
+        hipLaunchKernelGGL(col2im_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b.dcol, M, T, E, w, P, b.de);
+        NMTGAN_CHECK_LAUNCH("col2im_add");
+      }
+      raw += (int64_t)R * n;
+      col += n;
+    }
+    {
+      prof::Scope prof_scope(prof::OTHER, st);
+      const int vocab = t ? d->vocab_s : d->vocab;
+      NMTGAN_REQUIRE(hipMemsetAsync(tg.emb, 0, (size_t)vocab * E * sizeof(float), st) == hipSuccess, "disc_train: memset failed");
+      hipLaunchKernelGGL(embed_bwd_kernel, dim3((M * T + 3) / 4), dim3(256), 0, st, b.de, ids[t], M * T, E, vocab, 1.0f, tg.emb);
+      NMTGAN_CHECK_LAUNCH("disc_embed_bwd");
+    }
+  }
+  (void)F; (void)es;
   return 0;
 }
 

@@ -398,7 +398,7 @@ class Model(object):
         else:
             lr = float(_cfg_get(self.config, "generator.learning_rate", 1e-5))
             check(lib.nmtgan_rmsprop_update(ptr(tr["master"]), ptr(tr["ms"]), None, ptr(tr["grad"]), tr["n"], lr, 0.9, 0.0,
-                                            1e-10, 1.0 / world, ptr(tr["op"]), self._op, st), "nmtgan_rmsprop_update")
+                                            1e-10, 1.0 / world, 0.0, ptr(tr["op"]), self._op, st), "nmtgan_rmsprop_update")
         tr["steps"] += 1
         torch.cuda.synchronize(self.device)
         out = float(loss.item())

@@ -555,6 +555,83 @@ def disc_forward(Wd, dcfg: DisConfig, input_x_TB: np.ndarray, input_xs_TB: np.nd
     return torch.softmax(scores, dim=1)                               # :508
 
 
+# --------------------------------------------------------------------------- discriminator training step
+BN_DECAY = 0.9                                    # conv_batch_norm(decay=0.9), cnn_discriminator.py:22
+DIS_TRAINABLE_SKIP = ("moving_mean", "moving_variance")
+
+
+def _conv_bn_train_relu_max(e, Wd, scope, stats):
+    """cnn_layer.conv_op(is_train=True) + max_pool (cnn_discriminator.py:88-109, 22-33, 282-283): contrib batch_norm
+    in training mode normalises with the BATCH moments over (batch, time) per filter (tf.nn.moments: biased
+    variance, epsilon 1e-3) and - updates_collections=None - moves the moving statistics in place:
+    moving = moving * decay + batch * (1 - decay).  `stats[scope]` receives (batch mean, batch variance)."""
+    Wc = Wd[scope + "/self_model/W"]
+    w, E, _, n = Wc.shape
+    win = e.unfold(1, w, 1).permute(0, 1, 3, 2)
+    c = win.reshape(win.shape[0], win.shape[1], w * E) @ Wc.reshape(w * E, n) + Wd[scope + "/self_model/b"]
+    mean = c.mean(dim=(0, 1))
+    var = ((c - mean) ** 2).mean(dim=(0, 1))
+    stats[scope] = (mean.detach(), var.detach())
+    bn = scope + "/conv_batch_norm/bn/"
+    c = (c - mean) * torch.rsqrt(var + BN_EPS) * Wd[bn + "gamma"] + Wd[bn + "beta"]
+    return torch.relu(c).max(dim=1).values
+
+
+def disc_train_loss(Wd, dcfg: DisConfig, x_TB, xs_TB, y_2B):
+    """DisCNN.build_model (cnn_discriminator.py:248-345) for one tower, dropout keep 1.0 (train() feeds
+    drop_prob = 1.0, :640): returns (per-example softmax-CE losses [B], scores [B,2], batch BN stats)."""
+    stats = {}
+    feats = []
+    for source, ids_TB in ((False, x_TB), (True, xs_TB)):
+        ids = torch.from_numpy(np.ascontiguousarray(np.asarray(ids_TB).T)).long()
+        emb = Wd["discnn/model_self/" + ("embeddingtable_s" if source else "embeddingtable")]
+        e = emb[ids]
+        fmt = "discnn/conv_s_maxpool-%d" if source else "discnn/conv_maxpool-%d"
+        H = torch.cat([_conv_bn_train_relu_max(e, Wd, fmt % w, stats) for w in dcfg.filter_sizes], dim=1)
+        feats.append(_highway(H, Wd, "discnn/output_s_lin_0" if source else "discnn/output_lin_0",
+                              "discnn/transform_s_lin_0" if source else "discnn/transform_lin_0"))
+    scores = torch.cat(feats, dim=1) @ Wd["discnn/model_self/W"] + Wd["discnn/model_self/b"]
+    y = torch.from_numpy(np.ascontiguousarray(np.asarray(y_2B, np.float64).T)).to(scores.dtype)
+    losses = -(y * torch.log_softmax(scores, dim=1)).sum(dim=1)       # softmax_cross_entropy_with_logits :323
+    return losses, scores, stats
+
+
+def disc_train_grads(Wnp: Dict[str, np.ndarray], dcfg: DisConfig, x_TB, xs_TB, y_2B, dtype=torch.float64):
+    """optimizer.compute_gradients(losses, params) (cnn_discriminator.py:334): `losses` is the per-example vector, so
+    the gradient is that of its SUM; the reported loss is its mean (:343) and accuracy the argmax match rate (:326).
+    Returns (loss, accuracy, {trainable name: grad}, {bn scope: (batch mean, batch var)})."""
+    W = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in Wnp.items()}
+    for k, v in W.items():
+        if not k.endswith(DIS_TRAINABLE_SKIP):
+            v.requires_grad_(True)
+    losses, scores, stats = disc_train_loss(W, dcfg, x_TB, xs_TB, y_2B)
+    losses.sum().backward()
+    acc = float((scores.argmax(1).numpy() == np.asarray(y_2B).argmax(0)).mean())
+    G = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().numpy()
+         for k, v in W.items() if v.requires_grad}
+    return float(losses.mean().item()), acc, G, {k: (m.numpy(), v.numpy()) for k, (m, v) in stats.items()}
+
+
+def disc_train_step(W: Dict[str, np.ndarray], dcfg: DisConfig, x_TB, xs_TB, y_2B, ms: Dict[str, np.ndarray], lr=1e-4,
+                    first_step=False):
+    """One iteration of DisCNN.train (cnn_discriminator.py:561-591, 664-691), single tower, optimizer 'rmsprop'
+    (tf.train.RMSPropOptimizer(0.0001), :162-163): gradients clipped to [-1, 1] by value
+    (average_clip_gradient_by_value), RMSProp, BN moving statistics moved by the forward pass, and after the FIRST
+    step every trainable variable clipped to [-1, 1] (:690-691).  In place on W and ms; returns (loss, accuracy)."""
+    loss, acc, G, stats = disc_train_grads(W, dcfg, x_TB, xs_TB, y_2B)
+    G = {k: np.clip(g, -1.0, 1.0) for k, g in G.items()}
+    train = {k: W[k] for k in G}
+    rmsprop_apply(train, G, ms, lr)
+    for scope, (mean, var) in stats.items():
+        bn = scope + "/conv_batch_norm/bn/"
+        W[bn + "moving_mean"][...] = W[bn + "moving_mean"] * BN_DECAY + mean * (1.0 - BN_DECAY)
+        W[bn + "moving_variance"][...] = W[bn + "moving_variance"] * BN_DECAY + var * (1.0 - BN_DECAY)
+    if first_step:
+        for k in G:
+            np.clip(W[k], -1.0, 1.0, out=W[k])
+    return loss, acc
+
+
 # --------------------------------------------------------------------------- get_reward
 def get_reward(W, cfg, Wd, dcfg, x, x_to_maxlen, y_sample, y_sample_mask, rollnum, max_len,
                bias_num, uniforms: np.ndarray, mode: str = "full",

@@ -43,7 +43,8 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
              "nmtgan_addln_args": (_lib.AddLnArgs, "zero_row"), "nmtgan_attn_args": (_lib.AttnArgs, "q_op_dtype"),
              "nmtgan_attn_group_args": (_lib.AttnGroupArgs, "n_entries"), "nmtgan_sample_args": (_lib.SampleArgs, "out"),
              "nmtgan_generator": (_lib.Generator, "dec"), "nmtgan_discriminator": (_lib.Discriminator, "head_b"),
-             "nmtgan_reward_plan": (_lib.RewardPlan, "conv_bucket_taps")}
+             "nmtgan_reward_plan": (_lib.RewardPlan, "conv_bucket_taps"),
+             "nmtgan_disc_tower_params": (_lib.DiscTowerParams, "hw_tr"), "nmtgan_disc_params": (_lib.DiscParams, "head_b")}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "nmtgan.h"', 'int main(void) {']
     for cname, (_, last) in pairs.items():
         src.append('  printf("%s %%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (cname, cname, cname, last))
@@ -89,7 +90,7 @@ def test_entry_points_validate_before_launch():
     g.softmax_w = 12288
     assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 8, 8) > 0
     assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 200, 200) == 0    # LDS budget of the attention backward
-    assert _lib.lib.nmtgan_rmsprop_update(None, None, None, None, 16, 1e-5, 0.9, 0.0, 1e-10, 1.0, None, 0, None) != 0
+    assert _lib.lib.nmtgan_rmsprop_update(None, None, None, None, 16, 1e-5, 0.9, 0.0, 1e-10, 1.0, 0.0, None, 0, None) != 0
     assert _lib.lib.nmtgan_adadelta_update(4096, 4096, 4096, 4096, 16, 1e-3, 1.5, 1e-8, 1.0, None, 0, None) != 0
     with pytest.raises(_lib.NmtGanError):
         _lib.check(-2, "x")
