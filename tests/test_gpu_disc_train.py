@@ -108,3 +108,102 @@ def test_trained_weights_drive_inference_and_survive_a_checkpoint(cuda, tmp_path
     assert np.abs(p1 - p2).max() < 1e-5
     assert np.abs(p1 - p0).max() > 1e-4                  # training moved the scores
     assert np.isfinite(p1).all()
+
+
+def test_reference_geometry_gradient_is_the_directional_derivative(cuda):
+    """Size-independent property at the reference geometry (max_len 50, dim_word 512, 13 widths 1..49 with
+    110..590 filters, F = 4550, V = 32000), fp32 tier, 6 examples: along u = g/||g|| the symmetric difference of
+    the summed loss equals ||g|| within 3e-2 (the network is piecewise smooth: ReLU, max over time).  Learning rate 0,
+    so train_step leaves the trainable variables where they are."""
+    import nmt_gan_amd as N
+    from nmt_gan_amd import synthetic
+    Tn, E, V, B = 50, 512, 32000, 6
+    widths, nfs = synthetic.disc_filters(Tn)
+    Wd = synthetic.discriminator_weights(Tn, E, V, V, seed=1)
+    Wd["discnn/model_self/W"] = (Wd["discnn/model_self/W"] * np.float32(0.02)).astype(np.float32)   # unsaturated head
+    rng = np.random.default_rng(9)
+    x = rng.integers(4, V, (Tn, B)).astype(np.int32)
+    xs = rng.integers(4, V, (Tn, B)).astype(np.int32)
+    x[30:, 2] = 0
+    y = np.zeros((2, B), np.float32)
+    y[rng.integers(0, 2, B), np.arange(B)] = 1.0
+
+    def run(W, want_grads=False):
+        d = N.DisCNN(None, Tn, 2, V, B, E, widths, nfs, vocab_size_s=V, precision="fp32", optimizer='rmsprop')
+        d.learning_rate = 0.0
+        d.load_weights(W)
+        return d.train_step(x, y, xs, return_grads=want_grads)
+
+    L0, _, g = run(Wd, True)
+    norm = float(np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in g.values())))
+    assert np.isfinite(L0) and norm > 0
+    eps = 0.01 * abs(L0) * B / norm
+    plus, minus = dict(Wd), dict(Wd)
+    for k in g:
+        step = (eps * g[k].astype(np.float64) / norm).reshape(np.asarray(Wd[k]).shape)
+        plus[k] = (np.asarray(Wd[k], np.float64) + step).astype(np.float32)
+        minus[k] = (np.asarray(Wd[k], np.float64) - step).astype(np.float32)
+    slope = (run(plus)[0] - run(minus)[0]) * B / (2 * eps)
+    assert abs(slope - norm) < 3e-2 * norm, (slope, norm, L0, eps)
+
+
+_TWO_RANK_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+z = np.load(sys.argv[4], allow_pickle=False)
+from helpers import tiny_cfgs
+import nmt_gan_amd as N
+T = int(z["T"])
+_, dcfg = tiny_cfgs(T=T)
+d = N.DisCNN(None, T, 2, dcfg.vocab_size, 8, dcfg.dim_word, dcfg.filter_sizes, dcfg.num_filters,
+             vocab_size_s=dcfg.vocab_size_s, precision="fp32", optimizer='rmsprop')
+d.load_weights({k[2:]: z[k] for k in z.files if k.startswith("W:")})
+loss, acc = d.train_step(z["x"], z["y"], z["xs"])                    # every rank passes the WHOLE batch
+np.savez(sys.argv[5] + ".%d.npz" % dist.get_rank(), loss=np.float64(loss), acc=np.float64(acc), **d.get_weights())
+dist.barrier(); dist.destroy_process_group()
+print("rank ok")
+'''
+
+
+def test_two_rank_step_is_the_tower_average(cuda, tmp_path):
+    """N > 1 path (2 processes, gloo, both on cuda:0): the batch is cut in two like numpy.split
+    (cnn_discriminator.py:654-656), each tower normalises BatchNorm with its own half, gradients are averaged, then
+    clipped (average_clip_gradient_by_value) and applied.  Trainable variables end identical on both ranks and equal
+    to the oracle's step on the averaged fp64 gradients; loss and accuracy are the tower means."""
+    import os
+    import subprocess
+    import sys
+    dcfg, Wd, x, xs, y = _case(B=8)
+    halves = [O.disc_train_grads(Wd, dcfg, x[:, r * 4:(r + 1) * 4], xs[:, r * 4:(r + 1) * 4], y[:, r * 4:(r + 1) * 4])
+              for r in range(2)]
+    W = {k: np.array(v, np.float64) for k, v in Wd.items()}
+    G = {k: np.clip(0.5 * (halves[0][2][k] + halves[1][2][k]), -1.0, 1.0) for k in halves[0][2]}
+    train = {k: W[k] for k in G}
+    O.rmsprop_apply(train, G, {k: np.ones_like(v) for k, v in train.items()}, 1e-4)
+    for k in G:
+        np.clip(W[k], -1.0, 1.0, out=W[k])
+    inp = str(tmp_path / "in.npz")
+    np.savez(inp, x=x, xs=xs, y=y, T=T, **{"W:" + k: v for k, v in Wd.items()})
+    script = tmp_path / "worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = str(33500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), root, port, str(r), inp, str(tmp_path / "out")],
+                              env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "rank ok" in o, o
+    got = [dict(np.load(str(tmp_path / "out") + ".%d.npz" % r, allow_pickle=False)) for r in range(2)]
+    want_loss, want_acc = 0.5 * (halves[0][0] + halves[1][0]), 0.5 * (halves[0][1] + halves[1][1])
+    for r in range(2):
+        assert abs(float(got[r]["loss"]) - want_loss) <= 1e-5 * abs(want_loss)
+        assert float(got[r]["acc"]) == pytest.approx(want_acc)
+    for k in G:
+        assert np.array_equal(got[0][k], got[1][k]), k
+        d_ref = W[k] - np.asarray(Wd[k], np.float64)
+        d_got = got[0][k].astype(np.float64) - np.asarray(Wd[k], np.float64)
+        tol = 2e-3 * np.abs(d_ref).max() + 3 * np.finfo(np.float32).eps * max(np.abs(Wd[k]).max(), 1.0)
+        assert np.abs(d_got - d_ref).max() <= tol, (k, np.abs(d_got - d_ref).max(), tol)
