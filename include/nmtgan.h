@@ -377,9 +377,12 @@ int nmtgan_rmsprop_update(float* w, float* ms, float* mom, const float* grad, in
                           void* stream);
 /* tf.train.AdadeltaOptimizer() - the only other optimizer build_generate can select (model.py:111-119; defaults
  * lr 0.001, rho 0.95, eps 1e-8, both slots start at 0): accum = rho accum + (1-rho) g^2; upd = sqrt(accum_update + eps)
- * rsqrt(accum + eps) g; accum_update = rho accum_update + (1-rho) upd^2; w -= lr upd.  Same conventions as above. */
+ * rsqrt(accum + eps) g; accum_update = rho accum_update + (1-rho) upd^2; w -= lr upd.  Same conventions as above.
+ * The discriminator's default optimizer is AdadeltaOptimizer(learning_rate=1., rho=0.95, epsilon=1e-6)
+ * (cnn_discriminator.py:156-158). */
 int nmtgan_adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr,
-                           float rho, float eps, float grad_scale, void* w_op, int op_dtype, void* stream);
+                           float rho, float eps, float grad_scale, float grad_clip, void* w_op, int op_dtype,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Discriminator training step: one iteration of DisCNN.train (cnn_discriminator.py:664-691),

@@ -141,7 +141,7 @@ EXPORTS = {
     "nmtgan_pg_grads": (i32, [C.POINTER(Generator), C.POINTER(Generator), vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
                               sz, vp]),
     "nmtgan_rmsprop_update": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, i32, vp]),
-    "nmtgan_adadelta_update": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp]),
+    "nmtgan_adadelta_update": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]),
     "nmtgan_disc_train_workspace_bytes": (sz, [C.POINTER(Discriminator), i32]),
     "nmtgan_disc_train_grads": (i32, [C.POINTER(Discriminator), C.POINTER(DiscParams), C.POINTER(DiscParams), vp, vp, vp, i32,
                                       vp, vp, vp, sz, vp]),

@@ -50,7 +50,7 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
 int rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n, float lr, float decay, float momentum,
                    float eps, float grad_scale, float grad_clip, void* w_op, int op_dtype, hipStream_t st);
 int adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr, float rho,
-                    float eps, float grad_scale, void* w_op, int op_dtype, hipStream_t st);
+                    float eps, float grad_scale, float grad_clip, void* w_op, int op_dtype, hipStream_t st);
 int disc_train_workspace(const nmtgan_discriminator* d, int M, size_t* bytes);
 int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p, const nmtgan_disc_params* g, const int32_t* x,
                      const int32_t* xs, const float* labels, int M, float* loss, float* accuracy, void* ws, size_t ws_bytes,
@@ -184,8 +184,9 @@ int nmtgan_rmsprop_update(float* w, float* ms, float* mom, const float* grad, in
                         (hipStream_t)stream);
 }
 int nmtgan_adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr, float rho,
-                           float eps, float grad_scale, void* w_op, int op_dtype, void* stream) {
-  return adadelta_update(w, accum, accum_update, grad, n, lr, rho, eps, grad_scale, w_op, op_dtype, (hipStream_t)stream);
+                           float eps, float grad_scale, float grad_clip, void* w_op, int op_dtype, void* stream) {
+  return adadelta_update(w, accum, accum_update, grad, n, lr, rho, eps, grad_scale, grad_clip, w_op, op_dtype,
+                         (hipStream_t)stream);
 }
 size_t nmtgan_disc_train_workspace_bytes(const nmtgan_discriminator* d, int M) {
   size_t b = 0;

@@ -389,10 +389,11 @@ int rmsprop_update(float* w, float* ms, float* mom, const float* grad, int64_t n
 //   accum_update = rho accum_update + (1 - rho) upd^2;  w -= lr upd
 template <typename OpT>
 __global__ void adadelta_kernel(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr,
-                                float rho, float eps, float grad_scale, OpT* w_op) {
+                                float rho, float eps, float grad_scale, float grad_clip, OpT* w_op) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float g = grad[i] * grad_scale;
+  float g = grad[i] * grad_scale;
+  if (grad_clip > 0.f) g = fminf(fmaxf(g, -grad_clip), grad_clip);
   const float a = accum[i] * rho + g * g * (1.0f - rho);
   accum[i] = a;
   const float upd = sqrtf(accum_update[i] + eps) * rsqrtf(a + eps) * g;
@@ -403,7 +404,7 @@ __global__ void adadelta_kernel(float* w, float* accum, float* accum_update, con
 }
 
 int adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr, float rho,
-                    float eps, float grad_scale, void* w_op, int op_dtype, hipStream_t st) {
+                    float eps, float grad_scale, float grad_clip, void* w_op, int op_dtype, hipStream_t st) {
   prof::Scope prof_scope(prof::OTHER, st);
   if (n == 0) return 0;
   NMTGAN_REQUIRE(w && accum && accum_update && grad && n > 0, "adadelta_update: null pointer");
@@ -411,10 +412,10 @@ int adadelta_update(float* w, float* accum, float* accum_update, const float* gr
   dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (w_op && op_dtype == NMTGAN_BF16)
     hipLaunchKernelGGL(adadelta_kernel<bf16_t>, grid, block, 0, st, w, accum, accum_update, grad, n, lr, rho, eps, grad_scale,
-                       (bf16_t*)w_op);
+                       grad_clip, (bf16_t*)w_op);
   else
     hipLaunchKernelGGL(adadelta_kernel<float>, grid, block, 0, st, w, accum, accum_update, grad, n, lr, rho, eps, grad_scale,
-                       (float*)(op_dtype == NMTGAN_F32 ? w_op : nullptr));
+                       grad_clip, (float*)(op_dtype == NMTGAN_F32 ? w_op : nullptr));
   NMTGAN_CHECK_LAUNCH("adadelta");
   return 0;
 }

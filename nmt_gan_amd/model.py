@@ -393,7 +393,7 @@ class Model(object):
             if "accum" not in tr:
                 tr["accum"], tr["accum_update"] = torch.zeros_like(tr["master"]), torch.zeros_like(tr["master"])
             check(lib.nmtgan_adadelta_update(ptr(tr["master"]), ptr(tr["accum"]), ptr(tr["accum_update"]), ptr(tr["grad"]),
-                                             tr["n"], 0.001, 0.95, 1e-8, 1.0 / world, ptr(tr["op"]), self._op, st),
+                                             tr["n"], 0.001, 0.95, 1e-8, 1.0 / world, 0.0, ptr(tr["op"]), self._op, st),
                   "nmtgan_adadelta_update")
         else:
             lr = float(_cfg_get(self.config, "generator.learning_rate", 1e-5))

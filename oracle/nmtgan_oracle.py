@@ -613,7 +613,7 @@ def disc_train_grads(Wnp: Dict[str, np.ndarray], dcfg: DisConfig, x_TB, xs_TB, y
 
 
 def disc_train_step(W: Dict[str, np.ndarray], dcfg: DisConfig, x_TB, xs_TB, y_2B, ms: Dict[str, np.ndarray], lr=1e-4,
-                    first_step=False):
+                    first_step=False, adadelta=None):
     """One iteration of DisCNN.train (cnn_discriminator.py:561-591, 664-691), single tower, optimizer 'rmsprop'
     (tf.train.RMSPropOptimizer(0.0001), :162-163): gradients clipped to [-1, 1] by value
     (average_clip_gradient_by_value), RMSProp, BN moving statistics moved by the forward pass, and after the FIRST
@@ -621,7 +621,10 @@ def disc_train_step(W: Dict[str, np.ndarray], dcfg: DisConfig, x_TB, xs_TB, y_2B
     loss, acc, G, stats = disc_train_grads(W, dcfg, x_TB, xs_TB, y_2B)
     G = {k: np.clip(g, -1.0, 1.0) for k, g in G.items()}
     train = {k: W[k] for k in G}
-    rmsprop_apply(train, G, ms, lr)
+    if adadelta is not None:      # (accum, accum_update): AdadeltaOptimizer(learning_rate=1., rho=0.95, epsilon=1e-6), :156-158
+        adadelta_apply(train, G, adadelta[0], adadelta[1], lr=1.0, rho=0.95, epsilon=1e-6)
+    else:
+        rmsprop_apply(train, G, ms, lr)
     for scope, (mean, var) in stats.items():
         bn = scope + "/conv_batch_norm/bn/"
         W[bn + "moving_mean"][...] = W[bn + "moving_mean"] * BN_DECAY + mean * (1.0 - BN_DECAY)

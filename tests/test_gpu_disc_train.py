@@ -25,10 +25,10 @@ def _case(B=6, seed=3):
     return dcfg, Wd, x, xs, y
 
 
-def _disc(dcfg, Wd, precision):
+def _disc(dcfg, Wd, precision, optimizer='rmsprop'):
     import nmt_gan_amd as N
     d = N.DisCNN(None, T, 2, dcfg.vocab_size, 8, dcfg.dim_word, dcfg.filter_sizes, dcfg.num_filters,
-                 vocab_size_s=dcfg.vocab_size_s, precision=precision, optimizer='rmsprop')
+                 vocab_size_s=dcfg.vocab_size_s, precision=precision, optimizer=optimizer)
     d.load_weights(Wd)
     return d
 
@@ -70,6 +70,27 @@ def test_fp32_two_steps_match_oracle(cuda):
         tol = 2e-3 * np.abs(d_ref).max() + 3 * np.finfo(np.float32).eps * max(np.abs(Wd[k]).max(), 1.0)
         assert np.abs(d_got - d_ref).max() <= tol, (k, np.abs(d_got - d_ref).max(), tol)
     assert after["discnn/model_self/embeddingtable"].max() <= 1.0
+
+
+def test_fp32_two_adadelta_steps_match_oracle(cuda):
+    """The constructor's default optimizer, AdadeltaOptimizer(learning_rate=1., rho=0.95, epsilon=1e-6)
+    (cnn_discriminator.py:156-158): two steps against the oracle, tolerances as for RMSProp."""
+    dcfg, Wd, x, xs, y = _case()
+    W = {k: np.array(v, np.float64) for k, v in Wd.items()}
+    slots = tuple({k: np.zeros_like(v) for k, v in W.items() if not k.endswith(O.DIS_TRAINABLE_SKIP)} for _ in range(2))
+    ref = [O.disc_train_step(W, dcfg, x, xs, y, None, first_step=(i == 0), adadelta=slots) for i in range(2)]
+    d = _disc(dcfg, Wd, "fp32", optimizer='adadelta')
+    got = [d.train_step(x, y, xs) for _ in range(2)]
+    for (l, a), (rl, ra) in zip(got, ref):
+        assert abs(l - rl) <= 2e-4 * abs(rl) and a == pytest.approx(ra)
+    after = d.get_weights()
+    for k in W:
+        d_ref = W[k] - np.asarray(Wd[k], np.float64)
+        d_got = after[k].astype(np.float64) - np.asarray(Wd[k], np.float64)
+        tol = 3e-3 * np.abs(d_ref).max() + 3 * np.finfo(np.float32).eps * max(np.abs(Wd[k]).max(), 1.0)
+        assert np.abs(d_got - d_ref).max() <= tol, (k, np.abs(d_got - d_ref).max(), tol)
+    with pytest.raises(NotImplementedError):
+        _disc(dcfg, Wd, "fp32", optimizer='adam').train_step(x, y, xs)
 
 
 def test_bf16_gradients_close_to_autograd(cuda):

@@ -91,7 +91,7 @@ def test_entry_points_validate_before_launch():
     assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 8, 8) > 0
     assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 200, 200) == 0    # LDS budget of the attention backward
     assert _lib.lib.nmtgan_rmsprop_update(None, None, None, None, 16, 1e-5, 0.9, 0.0, 1e-10, 1.0, 0.0, None, 0, None) != 0
-    assert _lib.lib.nmtgan_adadelta_update(4096, 4096, 4096, 4096, 16, 1e-3, 1.5, 1e-8, 1.0, None, 0, None) != 0
+    assert _lib.lib.nmtgan_adadelta_update(4096, 4096, 4096, 4096, 16, 1e-3, 1.5, 1e-8, 1.0, 0.0, None, 0, None) != 0
     dd = _lib.Discriminator()                                      # discriminator training step
     dd.op_dtype, dd.max_len, dd.dim_word, dd.vocab, dd.vocab_s, dd.n_widths, dd.F, dd.Fp = 0, 12, 64, 512, 512, 2, 250, 256
     dd.widths[0], dd.widths[1], dd.n_filters[0], dd.n_filters[1] = 1, 5, 110, 150
