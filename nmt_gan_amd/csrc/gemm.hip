@@ -23,6 +23,8 @@
 
 #include <type_traits>
 
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -56,6 +58,9 @@ struct GemmParams {
   const float* scale; const float* shift; float* pooled; int64_t ld_pool;
   // stats epilogue (fused sampling)
   float2* stats;
+  // split-K (gemm_glds_kernel, LINEAR epilogue): grid.y = split_k slices of the k-tiles, each leaves its raw fp32
+  // partial in split_part[z][M][N]; splitk_finish_kernel adds the slices in order and applies the epilogue
+  int split_k; float* split_part;
 };
 constexpr int EPI_STATS = 2;
 
@@ -223,15 +228,55 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64)) void gemm_glds_kernel(G
   const int a_rd = (wm * 64 + fr) * BKB;
   const int b_rd = (BM + wn * 64 + fr) * BKB;
 
-  stage(0, 0);
+  const int nsl = p.split_k > 1 ? p.split_k : 1;
+  const int kt0 = (int)((int64_t)nkt * blockIdx.y / nsl), kt1 = (int)((int64_t)nkt * (blockIdx.y + 1) / nsl);
+  stage(0, kt0);
   int cur = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = kt0; kt < kt1; ++kt) {
     __syncthreads();                      // vmcnt(0) + barrier: tile kt landed, buffer cur^1 free
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
     compute_tile<OpT>(smem + cur * STAGE, a_rd, b_rd, fh, fsw, acc);
     cur ^= 1;
   }
+  if constexpr (EPI == NMTGAN_EPI_LINEAR) {
+    if (p.split_k > 1) {                  // raw partial of this k-slice
+      float* part = p.split_part + (int64_t)blockIdx.y * p.M * p.N;
+      const int m0 = bm0 + wm * 64, n0 = bn0 + wn * 64;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + j * 32 + fr;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            if (m < p.M) part[(int64_t)m * p.N + n] = acc[i][j][e];
+          }
+      }
+      return;
+    }
+  }
   epilogue<OpT, EPI>(p, acc, bm0 + wm * 64, bn0 + wn * 64, lane);
+}
+
+// out = epilogue(sum_z split_part[z]) with the LINEAR epilogue's semantics (bias, segment scale, ReLU, per-segment
+// destination and dtype); slices added in z order
+template <typename OpT>
+__global__ void splitk_finish_kernel(GemmParams p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)p.M * p.N) return;
+  const int n = (int)(i % p.N);
+  const int64_t m = i / p.N;
+  float v = 0.f;
+  for (int z = 0; z < p.split_k; ++z) v += p.split_part[(int64_t)z * p.M * p.N + i];
+  const int seg = (p.n_seg > 1) ? n / p.seg_width : 0;
+  const int nn = (p.n_seg > 1) ? n - seg * p.seg_width : n;
+  v = (v + (p.bias ? p.bias[n] : 0.f)) * pick3(p.seg_scale, seg);
+  if (p.relu) v = fmaxf(v, 0.f);
+  const int64_t ldo = pick3(p.ldo, seg);
+  if (pick3(p.out_f32, seg) != 0) reinterpret_cast<float*>(pick3(p.out, seg))[m * ldo + nn] = v;
+  else OpTraits<OpT>::store(reinterpret_cast<OpT*>(pick3(p.out, seg)) + m * ldo + nn, v);
 }
 
 // ------------------------------------------------------------------------------------------ pipelined kernel
@@ -859,10 +904,35 @@ static int launch_glds(GemmParams p, hipStream_t st) {
   }
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_glds_kernel<OpT, EPI, BM, BN>), dim3(p.ntm * p.ntn), dim3(64 * (BM / 64) * (BN / 64)), smem,
-                     st, p);
+  const int slices = (EPI == NMTGAN_EPI_LINEAR && p.split_k > 1) ? p.split_k : 1;
+  if (slices == 1) p.split_k = 0;
+  hipLaunchKernelGGL((gemm_glds_kernel<OpT, EPI, BM, BN>), dim3(p.ntm * p.ntn, slices), dim3(64 * (BM / 64) * (BN / 64)),
+                     smem, st, p);
   NMTGAN_CHECK_LAUNCH("gemm_glds");
+  if constexpr (EPI == NMTGAN_EPI_LINEAR) {
+    if (slices > 1) {
+      const int64_t n = (int64_t)p.M * p.N;
+      hipLaunchKernelGGL(splitk_finish_kernel<OpT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+      NMTGAN_CHECK_LAUNCH("gemm_splitk_finish");
+    }
+  }
   return 0;
+}
+
+// Split-K scratch of the calling thread (set by single-stream pipelines around their GEMM calls; never by the
+// two-stream rollout schedule, whose streams would share it).  With it, a LINEAR GEMM that would occupy few of the
+// 256 CUs with a long serial k-loop (M = 64 decode rows; the dW products of the update steps) is cut into k-slices.
+static thread_local float* g_splitk_buf = nullptr;
+static thread_local size_t g_splitk_bytes = 0;
+void set_gemm_splitk_scratch(void* buf, size_t bytes) { g_splitk_buf = (float*)buf; g_splitk_bytes = bytes; }
+static int choose_split_k(const GemmParams& p, int nkt) {
+  if (!g_splitk_buf) return 1;
+  const int64_t tiles = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  if (tiles > 64 || nkt < 8) return 1;
+  int64_t s = std::min<int64_t>(std::min<int64_t>(nkt / 2, (256 + tiles - 1) / tiles), 32);
+  const int64_t per = (int64_t)p.M * p.N * sizeof(float);
+  if (per > 0) s = std::min<int64_t>(s, (int64_t)(g_splitk_bytes / per));
+  return s >= 2 ? (int)s : 1;
 }
 
 template <typename OpT, int EPI>
@@ -936,6 +1006,12 @@ static int dispatch(const GemmParams& p, hipStream_t st) {
   if (pipe_ok && prefer_p8(p.M, p.N, nkt)) return launch_p8<OpT, EPI>(p, st);
   if (pipe_ok && (ov == 3 || (ov < 0 && tiles256 >= 192))) return launch_pipe<OpT, EPI>(p, st);
   if (ov == 256) return launch_glds<OpT, EPI, 256, 128>(p, st);
+  if constexpr (EPI == NMTGAN_EPI_LINEAR) {
+    GemmParams q = p;
+    q.split_k = choose_split_k(p, nkt);
+    q.split_part = g_splitk_buf;
+    return launch_glds<OpT, EPI, 128, 128>(q, st);
+  }
   return launch_glds<OpT, EPI, 128, 128>(p, st);
 }
 

@@ -12,6 +12,13 @@ bool gemm_stats_supported(int op_dtype, int V, int K);
 // cap on the grid of the persistent GEMM kernels launched by this thread (0 = one workgroup per CU);
 // the two-stream rollout schedule uses it to leave CUs to the concurrently running decode steps
 void set_gemm_wg_cap(int cap);
+// split-K scratch of the calling thread for the small LINEAR GEMMs (nullptr = off, the default); a pipeline that
+// issues all its GEMMs on ONE stream sets it around its launches
+void set_gemm_splitk_scratch(void* buf, size_t bytes);
+struct SplitKScope {
+  SplitKScope(void* buf, size_t bytes) { set_gemm_splitk_scratch(buf, bytes); }
+  ~SplitKScope() { set_gemm_splitk_scratch(nullptr, 0); }
+};
 int launch_logits_sample(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
                          const int64_t* u_off, int64_t u_add, int32_t* out, void* ws, hipStream_t st);
 size_t logits_sample_workspace(int M, int V);

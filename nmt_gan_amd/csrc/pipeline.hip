@@ -800,6 +800,7 @@ __global__ void fill_greedy_tables(int64_t* step_off, int n_steps, int B, int32_
 struct GreedyBufs {
   Act act; void *kbuf, *vbuf, *crossK, *crossV, *prK, *prV; float* logits;
   int64_t* step_off; int32_t *bos, *zeros, *blk, *tok_cur;
+  void* splitk; size_t splitk_bytes;
 };
 static void carve_greedy(Arena& ar, const nmtgan_generator* g, int B, int Ls, int T, GreedyBufs& b) {
   const int es = dtype_size(g->op_dtype), dm = g->d, N = g->n_blocks;
@@ -817,6 +818,9 @@ static void carve_greedy(Arena& ar, const nmtgan_generator* g, int B, int Ls, in
   b.zeros = ar.get<int32_t>(B);
   b.blk = ar.get<int32_t>(B);
   b.tok_cur = ar.get<int32_t>(B);
+  // split-K partials of the decode-step GEMMs (B rows against K = d .. 4d): up to 32 slices of the widest output
+  b.splitk_bytes = (size_t)32 * B * 4 * dm * sizeof(float);
+  b.splitk = ar.take(b.splitk_bytes);
 }
 int generate_workspace(const nmtgan_generator* g, int B, int Ls, int T, size_t* bytes) {
   NMTGAN_TRY(check_generator(g));
@@ -844,6 +848,7 @@ int generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* 
                      b.blk);
   NMTGAN_CHECK_LAUNCH("fill_greedy_tables");
   if (hipMemsetAsync(y, 0, (size_t)B * T * sizeof(int32_t), st) != hipSuccess) NMTGAN_FAIL(-3, "generate: memset failed");
+  SplitKScope split_k(b.splitk, b.splitk_bytes);      // single stream: the B-row step GEMMs are cut into k-slices
   for (int i = 0; i < T; ++i) {
     nmtgan_embed_args e{};
     e.table = g->emb_dst; e.timing = g->timing; e.vocab = V; e.max_pos = g->max_pos;

@@ -20,8 +20,6 @@
 
 namespace nmtgan {
 
-static inline char* at(const void* base, int64_t elems, int es) { return (char*)base + elems * es; }
-
 // ------------------------------------------------------------------------------------------ small kernels
 // out[c][r] = in[r][c] for r < R, 0 for R <= r < Rp  (cast TI -> TO on the way)
 // group > 0: row r starts at (r / group) * group_stride + (r % group) * ld_in (the overlapping conv windows of a
@@ -461,7 +459,8 @@ static int launch_cast_pad(int op, const float* in, int R, int C, int Cp, void* 
   return 0;
 }
 
-struct BwdScratch { void* dYo; void* dYT; void* XT; void* WT; float* colsum; };
+struct BwdScratch { void* dYo; void* dYT; void* XT; void* WT; float* colsum; void* splitk; size_t splitk_bytes; };
+static const size_t SPLITK_BYTES = (size_t)64 << 20;      // split-K partials of the few-tile dW products
 
 // Backward of Y = X . W + b with Wt[N][K] packed: gw.w <- dWt [N][K] fp32, gw.b <- colsum(dY), dX (optional) [M][K].
 // dY is fp32 [M][N] (dY_op == nullptr) or already in op dtype (dY_f32 == nullptr; no bias then).
@@ -568,6 +567,8 @@ static void carve_pg(Arena& ar, const nmtgan_generator* g, int B, int Ls, int T,
   b.s.XT = ar.take((int64_t)4 * d * Mp * es);
   b.s.WT = ar.take(std::max<int64_t>((int64_t)4 * d * d, (int64_t)d * V) * es);
   b.s.colsum = ar.get<float>((int64_t)COLSUM_CHUNKS * 4 * d);
+  b.s.splitk_bytes = SPLITK_BYTES;
+  b.s.splitk = ar.take(SPLITK_BYTES);
 }
 
 static int check_pg(const nmtgan_generator* g, const nmtgan_generator* gr, int B, int Ls, int T) {
@@ -609,10 +610,11 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
   PgBufs b;
   carve_pg(ar, g, B, Ls, T, b);
   NMTGAN_REQUIRE(!ar.overflow, "pg_grads: workspace too small (%zu bytes given)", ws_bytes);
-  const int op = g->op_dtype, d = g->d, N = g->n_blocks, H = g->heads, V = g->vocab_dst, es = dtype_size(op);
+  const int op = g->op_dtype, d = g->d, N = g->n_blocks, H = g->heads, V = g->vocab_dst;
   const int Me = B * Ls, Md = B * T;
   const float qscale = 1.0f / sqrtf((float)(d / H));
   const int f0[3] = {0, 0, 0};
+  SplitKScope split_k(b.s.splitk, b.s.splitk_bytes);     // everything below runs on ONE stream
 
   // ---------------- forward: encoder (model.py:486-543)
   {
@@ -761,7 +763,6 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
                        (float*)gr->emb_src);
     NMTGAN_CHECK_LAUNCH("embed_bwd");
   }
-  (void)es;
   return 0;
 }
 
@@ -1027,6 +1028,8 @@ static void carve_dt(Arena& ar, const nmtgan_discriminator* d, int M, DtBufs& b)
   b.s.XT = ar.take(std::max(max_rk, (int64_t)Fp * Mp) * es);
   b.s.WT = ar.take(std::max(max_kn, (int64_t)Fp * Fp) * es);
   b.s.colsum = ar.get<float>((int64_t)2 * COLSUM_CHUNKS * std::max<int64_t>(max_n, Fp));
+  b.s.splitk_bytes = SPLITK_BYTES;
+  b.s.splitk = ar.take(SPLITK_BYTES);
 }
 static int check_dt(const nmtgan_discriminator* d, const nmtgan_disc_params* p, const nmtgan_disc_params* g, int M) {
   NMTGAN_REQUIRE(d && p && g, "disc_train: null argument");
@@ -1062,7 +1065,8 @@ int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p,
   DtBufs b;
   carve_dt(ar, d, M, b);
   NMTGAN_REQUIRE(!ar.overflow, "disc_train: workspace too small (%zu bytes given)", ws_bytes);
-  const int T = d->max_len, E = d->dim_word, Fp = d->Fp, F = d->F, op = d->op_dtype, es = dtype_size(op);
+  const int T = d->max_len, E = d->dim_word, Fp = d->Fp, op = d->op_dtype;
+  SplitKScope split_k(b.s.splitk, b.s.splitk_bytes);     // everything below runs on ONE stream
   const nmtgan_disc_tower* tws[2] = {&d->tgt, &d->src};
   const nmtgan_disc_tower_params* tps[2] = {&p->tgt, &p->src};
   const nmtgan_disc_tower_params* tgs[2] = {&g->tgt, &g->src};
@@ -1164,7 +1168,6 @@ int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p,
       NMTGAN_CHECK_LAUNCH("disc_embed_bwd");
     }
   }
-  (void)F; (void)es;
   return 0;
 }
 
