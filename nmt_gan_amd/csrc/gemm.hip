@@ -984,7 +984,7 @@ static int dispatch(const GemmParams& p, hipStream_t st) {
   const int ov = tile_override();
   if (p.kbytes % BKB != 0 || ov == 0) return launch_generic<OpT, EPI>(p, st);
   // persistent pipelined kernels when the k-loop is long enough for their two-deep prefetch and there are at least
-  // NMTGAN_PIPE_MIN_TILES (32) tiles; else the simple double-buffered 128x128 kernel.  The threshold was 192 (3/4 of
+  // NMTGAN_PIPE_MIN_TILES (16) tiles; else the simple double-buffered 128x128 kernel.  The threshold was 192 (3/4 of
   // the CUs): the late rollout steps (1-12 k rows) then ran their K = 512 / 2048 GEMMs on the double-buffered
   // kernel, whose every k-tile waits out a full load latency (25-60 us per call against 12-20 on the pipelined one)
   const int nkt = p.kbytes / BKB;
@@ -1006,7 +1006,7 @@ static int dispatch(const GemmParams& p, hipStream_t st) {
     }
   }
   if (pipe_ok && prefer_p8(p.M, p.N, nkt)) return launch_p8<OpT, EPI>(p, st);
-  static const int pipe_min_tiles = [] { const char* e = getenv("NMTGAN_PIPE_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 32; }();
+  static const int pipe_min_tiles = [] { const char* e = getenv("NMTGAN_PIPE_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
   if (pipe_ok && (ov == 3 || (ov < 0 && tiles256 >= pipe_min_tiles))) return launch_pipe<OpT, EPI>(p, st);
   if (ov == 256) return launch_glds<OpT, EPI, 256, 128>(p, st);
   if constexpr (EPI == NMTGAN_EPI_LINEAR) {
