@@ -359,7 +359,8 @@ int nmtgan_teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, co
  *   vectors [N], tables emb_src/emb_dst/softmax_w [V][d]; op_dtype/timing/sizes of `grads` are ignored) and
  *   is overwritten.  loss: 1 float on the device; p_target (optional): [B][T] probability of Y[b,t].
  *   x [B][Ls], x_pad [B][Ls] (1 where x == 0), y [B][T], dec_in = shift_right(y), reward [B][T].
- *   Residual dropout is neutralised as on the rollout path; shared_embedding models are rejected;
+ *   Residual dropout is neutralised as on the rollout path; for a shared_embedding model the three table
+ *   gradients (emb_src, emb_dst, softmax_w of `grads`) name ONE buffer and are accumulated into it;
  *   max(Ls, T) is bounded by the 160 KiB of LDS the attention backward keeps its head slices and two score
  *   matrices in (90 at a head width of 64).
  * nmtgan_rmsprop_update: dense ApplyRMSProp over n contiguous parameters (ms += (g*g - ms)(1 - decay);
@@ -383,6 +384,15 @@ int nmtgan_rmsprop_update(float* w, float* ms, float* mom, const float* grad, in
 int nmtgan_adadelta_update(float* w, float* accum, float* accum_update, const float* grad, int64_t n, float lr,
                            float rho, float eps, float grad_scale, float grad_clip, void* w_op, int op_dtype,
                            void* stream);
+
+/* The discriminator's remaining optimizer choices (cnn_discriminator.py:153-161), same conventions:
+ * tf.train.GradientDescentOptimizer(0.0001): w -= lr g;  tf.train.AdamOptimizer() (lr 0.001, beta1 0.9, beta2 0.999,
+ * epsilon 1e-8): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps), t = the
+ * 1-based step count, slots start at 0. */
+int nmtgan_sgd_update(float* w, const float* grad, int64_t n, float lr, float grad_scale, float grad_clip, void* w_op,
+                      int op_dtype, void* stream);
+int nmtgan_adam_update(float* w, float* m, float* v, const float* grad, int64_t n, float lr, float beta1, float beta2,
+                       float eps, int t, float grad_scale, float grad_clip, void* w_op, int op_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Discriminator training step: one iteration of DisCNN.train (cnn_discriminator.py:664-691),

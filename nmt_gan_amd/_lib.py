@@ -147,6 +147,8 @@ EXPORTS = {
                                       vp, vp, vp, sz, vp]),
     "nmtgan_disc_fold_bn": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "nmtgan_clip_values": (i32, [vp, i64, f32, f32, vp, i32, vp]),
+    "nmtgan_sgd_update": (i32, [vp, vp, i64, f32, f32, f32, vp, i32, vp]),
+    "nmtgan_adam_update": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, f32, vp, i32, vp]),
     "nmtgan_profile_classes": (i32, []),
     "nmtgan_profile_start": (i32, []),
     "nmtgan_profile_stop": (i32, [C.POINTER(f64), C.POINTER(i64), i32]),

@@ -254,13 +254,12 @@ class DisCNN(object):
         y [2, B] one-hot labels, xs [max_len, B] source ids (the arrays dis_three_length_prepare feeds), dropout keep
         1.0 as train() feeds it.  Forward in training mode (BatchNorm batch moments, moving statistics moved),
         gradients of sum(losses), tower average + clip to [-1, 1] by value (share_function.py:413-441),
-        RMSProp(1e-4) (:162-163) or the constructor's default Adadelta(1., 0.95, 1e-6) (:156-158), and after the FIRST step every trainable variable clipped to [-1, 1] (:690-691).
+        the optimizer of the constructor (:153-166: Adam(), Adadelta(1., 0.95, 1e-6), SGD(1e-4), RMSProp(1e-4)), and after the FIRST step every trainable variable clipped to [-1, 1] (:690-691).
         With torch.distributed initialised each rank is one tower: the batch is cut evenly (numpy.split, :654-656),
         gradients are averaged with one all-reduce, loss and accuracy are tower means; every rank keeps its own
         BatchNorm moving statistics (the reference's towers race on the shared ones).  Returns (loss, accuracy)."""
-        if self.optimizer_name not in ('rmsprop', 'adadelta'):
-            raise NotImplementedError("DisCNN.train_step: dis_optimizer 'rmsprop' and 'adadelta' are built, not %r"
-                                      % (self.optimizer_name,))
+        if self.optimizer_name not in ('rmsprop', 'adadelta', 'adam', 'sgd'):
+            raise ValueError("optimizer must be adam, adadelta or sgd.")          # cnn_discriminator.py:166
         x = np.ascontiguousarray(np.asarray(x).T, dtype=np.int32)            # tf.transpose, :260-262
         xs = np.ascontiguousarray(np.asarray(xs).T, dtype=np.int32)
         lab = np.ascontiguousarray(np.asarray(y, dtype=np.float32).T)
@@ -303,6 +302,15 @@ class DisCNN(object):
             check(lib.nmtgan_adadelta_update(ptr(tr["master"]), ptr(tr["accum"]), ptr(tr["accum_update"]), ptr(tr["grad"]),
                                              tr["n"], 1.0, 0.95, 1e-6, 1.0 / world, 1.0, ptr(tr["op"]), self._op, st),
                   "nmtgan_adadelta_update")
+        elif self.optimizer_name == 'adam':       # tf.train.AdamOptimizer() defaults, :153-155
+            if "adam_m" not in tr:
+                tr["adam_m"], tr["adam_v"] = torch.zeros_like(tr["master"]), torch.zeros_like(tr["master"])
+            check(lib.nmtgan_adam_update(ptr(tr["master"]), ptr(tr["adam_m"]), ptr(tr["adam_v"]), ptr(tr["grad"]), tr["n"],
+                                         0.001, 0.9, 0.999, 1e-8, tr["steps"] + 1, 1.0 / world, 1.0, ptr(tr["op"]), self._op, st),
+                  "nmtgan_adam_update")
+        elif self.optimizer_name == 'sgd':        # GradientDescentOptimizer(0.0001), :159-161
+            check(lib.nmtgan_sgd_update(ptr(tr["master"]), ptr(tr["grad"]), tr["n"], self.learning_rate, 1.0 / world, 1.0,
+                                        ptr(tr["op"]), self._op, st), "nmtgan_sgd_update")
         else:
             check(lib.nmtgan_rmsprop_update(ptr(tr["master"]), ptr(tr["ms"]), None, ptr(tr["grad"]), tr["n"],
                                             self.learning_rate, 0.9, 0.0, 1e-10, 1.0 / world, 1.0, ptr(tr["op"]), self._op, st),

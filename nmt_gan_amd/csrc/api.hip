@@ -58,6 +58,8 @@ int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p,
 int disc_fold_bn(const float* b, const float* gamma, const float* beta, const float* mean, const float* var, int n,
                  float* scale, float* shift, hipStream_t st);
 int clip_values(float* w, int64_t n, float lo, float hi, void* w_op, int op_dtype, hipStream_t st);
+int sgd_adam_update(float* w, float* m, float* v, const float* grad, int64_t n, float lr, float b1, float b2, float eps,
+                    int t, float grad_scale, float grad_clip, void* w_op, int op_dtype, hipStream_t st);
 }  // namespace nmtgan
 
 using namespace nmtgan;
@@ -204,6 +206,17 @@ int nmtgan_disc_fold_bn(const float* conv_b, const float* gamma, const float* be
 }
 int nmtgan_clip_values(float* w, int64_t n, float lo, float hi, void* w_op, int op_dtype, void* stream) {
   return clip_values(w, n, lo, hi, w_op, op_dtype, (hipStream_t)stream);
+}
+int nmtgan_sgd_update(float* w, const float* grad, int64_t n, float lr, float grad_scale, float grad_clip, void* w_op,
+                      int op_dtype, void* stream) {
+  return sgd_adam_update(w, nullptr, nullptr, grad, n, lr, 0.f, 0.f, 0.f, 0, grad_scale, grad_clip, w_op, op_dtype,
+                         (hipStream_t)stream);
+}
+int nmtgan_adam_update(float* w, float* m, float* v, const float* grad, int64_t n, float lr, float beta1, float beta2,
+                       float eps, int t, float grad_scale, float grad_clip, void* w_op, int op_dtype, void* stream) {
+  if (!m || !v) { set_error("adam_update: null slot"); return -2; }
+  return sgd_adam_update(w, m, v, grad, n, lr, beta1, beta2, eps, t, grad_scale, grad_clip, w_op, op_dtype,
+                         (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -418,6 +418,47 @@ int adadelta_update(float* w, float* accum, float* accum_update, const float* gr
   return 0;
 }
 
+// The discriminator's two other optimizers (cnn_discriminator.py:153-161), dense, same conventions as above:
+//   tf.train.GradientDescentOptimizer(0.0001):  w -= lr g
+//   tf.train.AdamOptimizer() (lr 0.001, beta1 0.9, beta2 0.999, epsilon 1e-8; t = 1, 2, ..):
+//     m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  w -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)
+template <typename OpT>
+__global__ void sgd_adam_kernel(float* w, float* m, float* v, const float* grad, int64_t n, float lr_t, float b1, float b2,
+                                float eps, float grad_scale, float grad_clip, OpT* w_op) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float g = grad[i] * grad_scale;
+  if (grad_clip > 0.f) g = fminf(fmaxf(g, -grad_clip), grad_clip);
+  float step = lr_t * g;                                   // plain gradient descent when there are no slots
+  if (m) {
+    const float mi = b1 * m[i] + (1.0f - b1) * g, vi = b2 * v[i] + (1.0f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    step = lr_t * mi / (sqrtf(vi) + eps);
+  }
+  const float nw = w[i] - step;
+  w[i] = nw;
+  if (w_op) OpTraits<OpT>::store(w_op + i, nw);
+}
+int sgd_adam_update(float* w, float* m, float* v, const float* grad, int64_t n, float lr, float b1, float b2, float eps,
+                    int t, float grad_scale, float grad_clip, void* w_op, int op_dtype, hipStream_t st) {
+  prof::Scope prof_scope(prof::OTHER, st);
+  if (n == 0) return 0;
+  NMTGAN_REQUIRE(w && grad && n > 0 && ((m == nullptr) == (v == nullptr)), "sgd/adam update: null pointer");
+  NMTGAN_REQUIRE(lr >= 0.f && (!m || (t >= 1 && b1 >= 0.f && b1 < 1.f && b2 >= 0.f && b2 < 1.f && eps > 0.f)),
+                 "sgd/adam update: bad hyper-parameter");
+  const float lr_t = m ? (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t))) : lr;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (w_op && op_dtype == NMTGAN_BF16)
+    hipLaunchKernelGGL(sgd_adam_kernel<bf16_t>, grid, block, 0, st, w, m, v, grad, n, lr_t, b1, b2, eps, grad_scale, grad_clip,
+                       (bf16_t*)w_op);
+  else
+    hipLaunchKernelGGL(sgd_adam_kernel<float>, grid, block, 0, st, w, m, v, grad, n, lr_t, b1, b2, eps, grad_scale, grad_clip,
+                       (float*)(op_dtype == NMTGAN_F32 ? w_op : nullptr));
+  NMTGAN_CHECK_LAUNCH("sgd_adam");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ host helpers
 static int gemm_f32out(int op, const void* A, int64_t lda, int M, int K, int N, const void* Wt, const float* bias,
                        float* out, int64_t ldo, hipStream_t st) {
@@ -572,7 +613,7 @@ static void carve_pg(Arena& ar, const nmtgan_generator* g, int B, int Ls, int T,
 }
 
 static int check_pg(const nmtgan_generator* g, const nmtgan_generator* gr, int B, int Ls, int T) {
-  NMTGAN_REQUIRE(g && gr, "pg_grads: null model");
+  NMTGAN_REQUIRE(g != nullptr, "pg_grads: null model");
   NMTGAN_REQUIRE(g->op_dtype == NMTGAN_BF16 || g->op_dtype == NMTGAN_F32, "pg_grads: bad op_dtype");
   NMTGAN_REQUIRE(g->d > 0 && g->d % 64 == 0 && g->d <= 1024, "pg_grads: hidden_units must be a multiple of 64, <= 1024");
   NMTGAN_REQUIRE(g->heads > 0 && 64 % g->heads == 0 && g->d % g->heads == 0, "pg_grads: num_heads must divide 64");
@@ -585,15 +626,19 @@ static int check_pg(const nmtgan_generator* g, const nmtgan_generator* gr, int B
                    "pg_grads: max(Ls, T) = %d with head width %d exceeds the LDS budget of the attention backward", L,
                    g->d / g->heads);
   }
-  NMTGAN_REQUIRE((const void*)g->emb_dst != g->softmax_w && g->emb_src != g->emb_dst,
-                 "pg_grads: shared_embedding is not supported by the update step");
+  if (!gr) return 0;                       // workspace query: shapes only
   NMTGAN_REQUIRE(gr->emb_src && gr->emb_dst && gr->softmax_w, "pg_grads: null gradient table");
+  // shared_embedding (model.py:777-818: one table for source, target and softmax): the three gradient pointers
+  // name ONE buffer and the contributions are accumulated; anything in between is a caller error
+  const bool shared = (const void*)gr->emb_dst == gr->softmax_w;
+  NMTGAN_REQUIRE(shared ? gr->emb_src == gr->emb_dst && g->emb_src == g->emb_dst && g->vocab_src == g->vocab_dst
+                        : gr->emb_src != gr->emb_dst && (const void*)gr->emb_src != gr->softmax_w,
+                 "pg_grads: gradient tables must be all distinct or all the same buffer (shared_embedding)");
   return 0;
 }
 
 int pg_workspace(const nmtgan_generator* g, int B, int Ls, int T, size_t* bytes) {
-  nmtgan_generator dummy = *g;
-  NMTGAN_TRY(check_pg(g, &dummy, B, Ls, T));
+  NMTGAN_TRY(check_pg(g, nullptr, B, Ls, T));
   Arena ar(nullptr, 0);
   PgBufs b;
   carve_pg(ar, g, B, Ls, T, b);
@@ -604,6 +649,7 @@ int pg_workspace(const nmtgan_generator* g, int B, int Ls, int T, size_t* bytes)
 int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_t* x, const uint8_t* x_pad, const int32_t* y,
              const int32_t* dec_in, const float* reward, int B, int Ls, int T, float* loss, float* p_target, void* ws,
              size_t ws_bytes, hipStream_t st) {
+  NMTGAN_REQUIRE(gr != nullptr, "pg_grads: null gradient struct");
   NMTGAN_TRY(check_pg(g, gr, B, Ls, T));
   NMTGAN_REQUIRE(x && x_pad && y && dec_in && reward && loss && ws, "pg_grads: null pointer");
   Arena ar(ws, ws_bytes);
@@ -730,8 +776,9 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
   // decoder embedding: h = 2 * sqrt(d) * E_dst[shift_right(Y)] + timing (model.py:565)
   {
     prof::Scope prof_scope(prof::OTHER, st);
-    NMTGAN_REQUIRE(hipMemsetAsync((void*)gr->emb_dst, 0, (size_t)g->vocab_dst * d * sizeof(float), st) == hipSuccess,
-                   "pg_grads: memset failed");
+    if ((const void*)gr->emb_dst != gr->softmax_w)     // shared table: add to the softmax gradient written above
+      NMTGAN_REQUIRE(hipMemsetAsync((void*)gr->emb_dst, 0, (size_t)g->vocab_dst * d * sizeof(float), st) == hipSuccess,
+                     "pg_grads: memset failed");
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((Md + 3) / 4), dim3(256), 0, st, b.dx, dec_in, Md, d, g->vocab_dst,
                        2.0f * g->emb_mult, (float*)gr->emb_dst);
     NMTGAN_CHECK_LAUNCH("embed_bwd");
@@ -757,8 +804,9 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
   }
   {
     prof::Scope prof_scope(prof::OTHER, st);
-    NMTGAN_REQUIRE(hipMemsetAsync((void*)gr->emb_src, 0, (size_t)g->vocab_src * d * sizeof(float), st) == hipSuccess,
-                   "pg_grads: memset failed");
+    if (gr->emb_src != gr->emb_dst)
+      NMTGAN_REQUIRE(hipMemsetAsync((void*)gr->emb_src, 0, (size_t)g->vocab_src * d * sizeof(float), st) == hipSuccess,
+                     "pg_grads: memset failed");
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((Me + 3) / 4), dim3(256), 0, st, b.denc, x, Me, d, g->vocab_src, g->emb_mult,
                        (float*)gr->emb_src);
     NMTGAN_CHECK_LAUNCH("embed_bwd");

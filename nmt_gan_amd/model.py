@@ -232,9 +232,12 @@ class Model(object):
         """(TF variable name, kind, path into the nmtgan_generator struct) of every trainable variable
         (SURVEY Appendix C).  kind: mat = dense kernel packed Wt[N][K] and read in op dtype, vec = fp32 vector,
         tab = fp32 embedding table, smx = softmax table [V][d] read in op dtype."""
-        specs = [("embedding/src_embedding/kernel", "tab", ("emb_src",)),
-                 ("embedding/dst_embedding/kernel", "tab", ("emb_dst",)),
-                 ("embedding/softmax/kernel", "smx", ("softmax_w",))]
+        if self.shared_embedding:          # one table read as source / target embedding (fp32) and softmax (op dtype)
+            specs = [("embedding/shared/kernel", "shr", ("emb_src",))]
+        else:
+            specs = [("embedding/src_embedding/kernel", "tab", ("emb_src",)),
+                     ("embedding/dst_embedding/kernel", "tab", ("emb_dst",)),
+                     ("embedding/softmax/kernel", "smx", ("softmax_w",))]
 
         def dense(name, path):
             specs.append((name + "/kernel", "mat", path + ("w",)))
@@ -273,8 +276,6 @@ class Model(object):
         re-pointed into these buffers; a second struct with the same shape names the gradients."""
         if self._train is not None:
             return self._train
-        if self.shared_embedding:
-            raise NotImplementedError("generate_step_and_update: shared_embedding models are not supported")
         W = self._W_src
         if W is None:
             raise RuntimeError("Model: init_and_restore()/load_weights() has not been called")
@@ -312,6 +313,10 @@ class Model(object):
             use_op = opc is not None and kind in ("mat", "smx")
             put(c, path, (opc.data_ptr() + 2 * o) if use_op else (master.data_ptr() + 4 * o))
             put(gc, path, grad.data_ptr() + 4 * o)
+            if kind == "shr":              # the three roles of the shared table; ONE gradient buffer accumulates them
+                c.emb_dst = c.emb_src
+                c.softmax_w = (opc.data_ptr() + 2 * o) if opc is not None else c.emb_src
+                gc.emb_dst = gc.softmax_w = gc.emb_src
             index[name] = (kind, o, a.size)
         timing = [t for t in self._keep if t.data_ptr() == old.timing]
         self._keep = timing + [master, grad, ms] + ([opc] if opc is not None else [])

@@ -612,8 +612,19 @@ def disc_train_grads(Wnp: Dict[str, np.ndarray], dcfg: DisConfig, x_TB, xs_TB, y
     return float(losses.mean().item()), acc, G, {k: (m.numpy(), v.numpy()) for k, (m, v) in stats.items()}
 
 
+def adam_apply(W, G, m, v, t: int, lr: float = 0.001, beta1: float = 0.9, beta2: float = 0.999, epsilon: float = 1e-8):
+    """tf.train.AdamOptimizer() defaults (cnn_discriminator.py:153-155), dense ApplyAdam as recalled from TF 1.x:
+    lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t); m, v moving averages from 0; var -= lr_t m / (sqrt(v) + epsilon)."""
+    lr_t = lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    for k in W:
+        g = np.asarray(G[k], W[k].dtype)
+        m[k][...] = beta1 * m[k] + (1.0 - beta1) * g
+        v[k][...] = beta2 * v[k] + (1.0 - beta2) * g * g
+        W[k] -= lr_t * m[k] / (np.sqrt(v[k]) + epsilon)
+
+
 def disc_train_step(W: Dict[str, np.ndarray], dcfg: DisConfig, x_TB, xs_TB, y_2B, ms: Dict[str, np.ndarray], lr=1e-4,
-                    first_step=False, adadelta=None):
+                    first_step=False, adadelta=None, adam=None, sgd=False):
     """One iteration of DisCNN.train (cnn_discriminator.py:561-591, 664-691), single tower, optimizer 'rmsprop'
     (tf.train.RMSPropOptimizer(0.0001), :162-163): gradients clipped to [-1, 1] by value
     (average_clip_gradient_by_value), RMSProp, BN moving statistics moved by the forward pass, and after the FIRST
@@ -623,6 +634,11 @@ def disc_train_step(W: Dict[str, np.ndarray], dcfg: DisConfig, x_TB, xs_TB, y_2B
     train = {k: W[k] for k in G}
     if adadelta is not None:      # (accum, accum_update): AdadeltaOptimizer(learning_rate=1., rho=0.95, epsilon=1e-6), :156-158
         adadelta_apply(train, G, adadelta[0], adadelta[1], lr=1.0, rho=0.95, epsilon=1e-6)
+    elif adam is not None:        # (m, v, t): AdamOptimizer(), :153-155
+        adam_apply(train, G, adam[0], adam[1], adam[2])
+    elif sgd:                     # GradientDescentOptimizer(0.0001), :159-161
+        for k in train:
+            train[k] -= lr * G[k]
     else:
         rmsprop_apply(train, G, ms, lr)
     for scope, (mean, var) in stats.items():

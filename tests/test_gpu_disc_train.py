@@ -89,8 +89,37 @@ def test_fp32_two_adadelta_steps_match_oracle(cuda):
         d_got = after[k].astype(np.float64) - np.asarray(Wd[k], np.float64)
         tol = 3e-3 * np.abs(d_ref).max() + 3 * np.finfo(np.float32).eps * max(np.abs(Wd[k]).max(), 1.0)
         assert np.abs(d_got - d_ref).max() <= tol, (k, np.abs(d_got - d_ref).max(), tol)
-    with pytest.raises(NotImplementedError):
-        _disc(dcfg, Wd, "fp32", optimizer='adam').train_step(x, y, xs)
+    with pytest.raises(ValueError):
+        _disc(dcfg, Wd, "fp32", optimizer='momentum').train_step(x, y, xs)
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_fp32_two_adam_and_sgd_steps_match_oracle(cuda, optimizer):
+    """The remaining dis_optimizer choices (cnn_discriminator.py:153-161): AdamOptimizer() and
+    GradientDescentOptimizer(0.0001), two steps against the oracle.  The conv biases are left out of the Adam
+    comparison: BatchNorm removes the mean, so their true gradient is 0 and what arrives is rounding noise (1e-14 in
+    the fp64 oracle, 1e-7 in fp32), which Adam's m / (sqrt(v) + 1e-8) turns into a full-size step in fp32."""
+    dcfg, Wd, x, xs, y = _case()
+    W = {k: np.array(v, np.float64) for k, v in Wd.items()}
+    tr = [k for k in W if not k.endswith(O.DIS_TRAINABLE_SKIP)]
+    m, v = {k: np.zeros_like(W[k]) for k in tr}, {k: np.zeros_like(W[k]) for k in tr}
+    for i in range(2):
+        O.disc_train_step(W, dcfg, x, xs, y, None, first_step=(i == 0), adam=(m, v, i + 1) if optimizer == "adam" else None,
+                          sgd=optimizer == "sgd")
+    d = _disc(dcfg, Wd, "fp32", optimizer=optimizer)
+    for _ in range(2):
+        d.train_step(x, y, xs)
+    after = d.get_weights()
+    for k in W:
+        if optimizer == "adam" and k.endswith("self_model/b"):
+            continue
+        d_ref = W[k] - np.asarray(Wd[k], np.float64)
+        d_got = after[k].astype(np.float64) - np.asarray(Wd[k], np.float64)
+        # Adam divides by sqrt(v): an element whose gradient is 1e-4 of the tensor's largest carries the tensor-scale
+        # gradient error (1e-4) at full size into its step, hence 2e-2 of the largest step for Adam, 3e-3 for SGD
+        tol = (2e-2 if optimizer == "adam" else 3e-3) * np.abs(d_ref).max() + \
+            3 * np.finfo(np.float32).eps * max(np.abs(Wd[k]).max(), 1.0)
+        assert np.abs(d_got - d_ref).max() <= tol, (k, np.abs(d_got - d_ref).max(), tol)
 
 
 def test_bf16_gradients_close_to_autograd(cuda):

@@ -130,15 +130,29 @@ def test_update_rejects_what_it_does_not_support(cuda):
     m = _model(gcfg, Wg, "fp32", y.shape[1])
     with pytest.raises(ValueError):
         m.generate_step_and_update(x, y, reward[:, :-1])
+
+
+def test_fp32_shared_embedding_update_matches_oracle(cuda):
+    """train.shared_embedding: True (model.py:777-818): one table serves as source embedding, target embedding and
+    softmax matrix; its gradient is the sum of the three contributions.  Loss 1e-5, gradients 1e-4, one RMSProp step."""
     import nmt_gan_amd as N
+    gcfg, _ = tiny_cfgs(T=12, shared=True)
+    Wg = O.init_generator_weights(gcfg, 0)
+    assert "embedding/shared/kernel" in Wg
+    _, _, _, x, y, mask, reward = _case()
+    ref_loss, ref_g = O.pg_loss_and_grads(Wg, gcfg, x, y, reward)
     cfg = facade_config(gcfg)
-    cfg["train"] = Cfg(shared_embedding=True)
-    shared = N.Model(cfg, precision="fp32")
-    shared.build_generate(y.shape[1])
-    Ws = dict(Wg, **{"embedding/shared/kernel": Wg["embedding/softmax/kernel"]})
-    shared.init_and_restore(weights=Ws)
-    with pytest.raises(NotImplementedError):
-        shared.generate_step_and_update(x, y, reward)
+    cfg["generator"] = Cfg(learning_rate=1e-5)
+    m = N.Model(cfg, precision="fp32")
+    m.build_generate(y.shape[1])
+    m.init_and_restore(weights=Wg)
+    loss, grads = m.generate_step_and_update(x, y, reward, return_grads=True)
+    assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss)
+    assert set(grads) == set(ref_g)
+    worst = max((rel_err(grads[k], ref_g[k]), k) for k in ref_g if np.abs(ref_g[k]).max() > 0)
+    assert worst[0] < 1e-4, worst
+    assert np.isfinite(m.generate_step_and_update(x, y, reward))        # and the updated shared table still drives the path
+    assert m.generate_step(x).shape == y.shape
 
 
 def test_fp32_two_adadelta_updates_match_oracle(cuda):

@@ -84,14 +84,18 @@ def test_entry_points_validate_before_launch():
     assert b"multiple of 8" in _lib.lib.nmtgan_last_error()
     g.vocab_dst = 512
     assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 8, 300) == 0      # T beyond the timing table
-    g.emb_src, g.emb_dst, g.softmax_w = 4096, 8192, 8192                        # shared embedding/softmax table
-    assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 8, 8) == 0
-    assert b"shared_embedding" in _lib.lib.nmtgan_last_error()
-    g.softmax_w = 12288
     assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 8, 8) > 0
+    gr = _lib.Generator()                                                       # two of three gradient tables aliased
+    gr.emb_src, gr.emb_dst, gr.softmax_w = 4096, 8192, 8192
+    assert _lib.lib.nmtgan_pg_grads(C.byref(g), C.byref(gr), None, None, None, None, None, 4, 8, 8, None, None, None, 0,
+                                    None) != 0
+    assert b"shared_embedding" in _lib.lib.nmtgan_last_error()
     assert _lib.lib.nmtgan_pg_workspace_bytes(C.byref(g), 4, 200, 200) == 0    # LDS budget of the attention backward
     assert _lib.lib.nmtgan_rmsprop_update(None, None, None, None, 16, 1e-5, 0.9, 0.0, 1e-10, 1.0, 0.0, None, 0, None) != 0
     assert _lib.lib.nmtgan_adadelta_update(4096, 4096, 4096, 4096, 16, 1e-3, 1.5, 1e-8, 1.0, 0.0, None, 0, None) != 0
+    assert _lib.lib.nmtgan_adam_update(4096, None, None, 4096, 16, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, 0.0, None, 0, None) != 0
+    assert _lib.lib.nmtgan_adam_update(4096, 4096, 4096, 4096, 16, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, 0.0, None, 0, None) != 0
+    assert _lib.lib.nmtgan_sgd_update(None, None, 16, 1e-4, 1.0, 0.0, None, 0, None) != 0
     dd = _lib.Discriminator()                                      # discriminator training step
     dd.op_dtype, dd.max_len, dd.dim_word, dd.vocab, dd.vocab_s, dd.n_widths, dd.F, dd.Fp = 0, 12, 64, 512, 512, 2, 250, 256
     dd.widths[0], dd.widths[1], dd.n_filters[0], dd.n_filters[1] = 1, 5, 110, 150
