@@ -34,6 +34,44 @@ def extend_sentence_to_maxlen(seqs, maxlen=50):
     return x
 
 
+def prepare_gan_dis_data(train_data_source, train_data_target, gan_dis_source_data, gan_dis_positive_data,
+                         num=None, reshuf=True, seed=None):
+    """Reference: share_function.py:17-36 (+ shuffle.py): draw `num` aligned (source, target) line pairs of the training
+    corpus as the discriminator's source / positive data for this GAN iteration (gan_train.py:137-144).  The
+    reference shells out (`python shuffle.py`, `head -n`, `rm`) through os.popen without waiting for the commands; here
+    the same files are produced in-process: lines joined pairwise, shuffled (random.shuffle; `seed` is a keyword-only
+    style extension for reproducible runs), the first `num` pairs written.  With reshuf=False the reference reads
+    existing `<file>.shuf` copies; they are used when present, else the corpus order is kept.  The `.shuf`
+    intermediates are removed as the reference does.  Returns num."""
+    import os
+    import random
+
+    def read(path):
+        with open(path, 'r') as f:
+            return [l.rstrip('\n') for l in f]
+
+    src_path, dst_path = train_data_source, train_data_target
+    if not reshuf and os.path.exists(src_path + '.shuf') and os.path.exists(dst_path + '.shuf'):
+        src_path, dst_path = src_path + '.shuf', dst_path + '.shuf'
+    src, dst = read(src_path), read(dst_path)
+    if len(src) != len(dst):
+        raise ValueError("prepare_gan_dis_data: %s and %s have different line counts" % (src_path, dst_path))
+    total = len(read(train_data_source))
+    if num is None or num > total:
+        num = total
+    pairs = list(zip(src, dst))
+    if reshuf:
+        (random.Random(seed) if seed is not None else random).shuffle(pairs)
+    with open(gan_dis_source_data, 'w') as fs, open(gan_dis_positive_data, 'w') as fp:
+        for a, b in pairs[:num]:
+            fs.write(a + '\n')
+            fp.write(b + '\n')
+    for path in (train_data_source + '.shuf', train_data_target + '.shuf'):
+        if os.path.exists(path):
+            os.remove(path)
+    return num
+
+
 def timing_signal(length, channels):
     """Sinusoid table of add_timing_signal_1d (tensor2tensor/common_attention.py:55-67), evaluated
     in fp32 like the TF graph: sines in the first half of the channels, cosines in the second."""

@@ -131,6 +131,30 @@ def test_reference_named_helpers():
     assert cfg.a == 1 and cfg.train.shared_embedding is False
 
 
+def test_prepare_gan_dis_data(tmp_path):
+    """share_function.py:17-36: num aligned (source, target) pairs, shuffled jointly; intermediates removed."""
+    import nmt_gan_amd as N
+    src = ["s%d a b" % i for i in range(20)]
+    dst = ["t%d c d" % i for i in range(20)]
+    fs, ft = tmp_path / "train.src", tmp_path / "train.dst"
+    fs.write_text("\n".join(src) + "\n")
+    ft.write_text("\n".join(dst) + "\n")
+    out_s, out_p = tmp_path / "gan.src", tmp_path / "gan.pos"
+    assert N.prepare_gan_dis_data(str(fs), str(ft), str(out_s), str(out_p), num=7, reshuf=True, seed=3) == 7
+    got_s, got_p = out_s.read_text().splitlines(), out_p.read_text().splitlines()
+    assert len(got_s) == len(got_p) == 7 and len(set(got_s)) == 7
+    assert all(a.split()[0][1:] == b.split()[0][1:] for a, b in zip(got_s, got_p))       # pairs stay aligned
+    assert got_s != src[:7]                                                               # and were shuffled
+    assert N.prepare_gan_dis_data(str(fs), str(ft), str(out_s), str(out_p), num=None, reshuf=False) == 20
+    assert out_s.read_text().splitlines() == src and out_p.read_text().splitlines() == dst
+    assert N.prepare_gan_dis_data(str(fs), str(ft), str(out_s), str(out_p), num=99, reshuf=True) == 20
+    assert sorted(out_s.read_text().splitlines()) == sorted(src)
+    ft.write_text("\n".join(dst[:5]) + "\n")
+    with pytest.raises(ValueError):
+        N.prepare_gan_dis_data(str(fs), str(ft), str(out_s), str(out_p))
+    assert not (tmp_path / "train.src.shuf").exists()
+
+
 def test_rollout_plan_invariants():
     import nmt_gan_amd as N
     rng = np.random.default_rng(0)
