@@ -13,6 +13,10 @@
  *    synchronises; no hipMalloc/hipFree inside.
  *  - return 0 on success, a negative code on error; nmtgan_last_error() gives the thread-local
  *    message.  Shapes are validated on the host before any launch.
+ *  - state kept by the library is thread-local and set only for the duration of a call (error text, the
+ *    workgroup cap and the split-K scratch the pipelines set around their own GEMM launches) plus one event
+ *    pool per device for the two-stream schedule: calls from different threads / on different streams do not
+ *    interfere, as long as concurrent calls use different workspaces.
  *  - "op dtype" = the MFMA operand / KV-cache / activation-copy element type of a packed model:
  *    NMTGAN_BF16 (bf16 operands, fp32 accumulate; the throughput tier) or NMTGAN_F32 (exact fp32
  *    MFMA; the 1e-5 parity tier).  Residual stream, LayerNorm, softmax, CDF are fp32/fp64 always.
