@@ -867,8 +867,8 @@ static int launch_col_moments(const float* raw, int R, int C, float* mean, float
 __global__ void bn_relu_max_kernel(const float* raw, const float* mean, const float* var, const float* gamma,
                                    const float* beta, int M, int P, int n, float* pooled, int64_t ld_pool, int32_t* arg,
                                    int64_t ld_arg, float* moving_mean, float* moving_var, float decay) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = blockIdx.y;
+  const int f = blockIdx.y * blockDim.x + threadIdx.x;      // sentences on grid.x (no 65535 limit), filter tiles on grid.y
+  const int m = blockIdx.x;
   if (f >= n) return;
   const float mu = mean[f], rs = rsqrtf(var[f] + 1e-3f), g = gamma[f], b = beta[f];
   float best = 0.f;
@@ -908,8 +908,8 @@ __global__ void bn_bwd_stats_kernel(const float* dH, int64_t ld_dh, const float*
 __global__ void bn_bwd_dense_kernel(const float* dH, int64_t ld_dh, const float* pooled, int64_t ld_pool, const int32_t* arg,
                                     int64_t ld_arg, const float* raw, const float* mean, const float* var, const float* gamma,
                                     const float* dgamma, const float* dbeta, int M, int P, int n, float* dc) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = blockIdx.y;
+  const int f = blockIdx.y * blockDim.x + threadIdx.x;      // windows on grid.x, filter tiles on grid.y
+  const int r = blockIdx.x;
   if (f >= n) return;
   const int m = r / P, p = r % P;
   const float mu = mean[f], rs = rsqrtf(var[f] + 1e-3f);
@@ -1140,7 +1140,7 @@ int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p,
       NMTGAN_TRY(launch_col_moments(raw, R, n, b.mean[t] + col, b.var[t] + col, b.s.colsum, st));
       {
         prof::Scope prof_scope(prof::OTHER, st);
-        hipLaunchKernelGGL(bn_relu_max_kernel, dim3((n + 63) / 64, M), dim3(64), 0, st, raw, b.mean[t] + col, b.var[t] + col,
+        hipLaunchKernelGGL(bn_relu_max_kernel, dim3(M, (n + 63) / 64), dim3(64), 0, st, raw, b.mean[t] + col, b.var[t] + col,
                            tp.gamma + col, tp.beta + col, M, P, n, b.pooled[t] + col, (int64_t)Fp, b.arg[t] + col, (int64_t)Fp,
                            tp.moving_mean + col, tp.moving_var + col, 0.9f);
         NMTGAN_CHECK_LAUNCH("bn_relu_max");
@@ -1192,7 +1192,7 @@ int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p,
         hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((n + 63) / 64), dim3(64), 0, st, b.dH + col, (int64_t)Fp, b.pooled[t] + col,
                            (int64_t)Fp, b.arg[t] + col, (int64_t)Fp, raw, b.mean[t] + col, b.var[t] + col, M, P, n,
                            tg.gamma + col, tg.beta + col);
-        hipLaunchKernelGGL(bn_bwd_dense_kernel, dim3((n + 63) / 64, R), dim3(64), 0, st, b.dH + col, (int64_t)Fp,
+        hipLaunchKernelGGL(bn_bwd_dense_kernel, dim3(R, (n + 63) / 64), dim3(64), 0, st, b.dH + col, (int64_t)Fp,
                            b.pooled[t] + col, (int64_t)Fp, b.arg[t] + col, (int64_t)Fp, raw, b.mean[t] + col, b.var[t] + col,
                            tp.gamma + col, tg.gamma + col, tg.beta + col, M, P, n, b.dc);
         NMTGAN_CHECK_LAUNCH("bn_bwd");
