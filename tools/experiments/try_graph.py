@@ -1,7 +1,7 @@
 """Experiment: one get_reward (C2) as plain stream launches vs one HIP-graph replay."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import nmt_gan_amd as N

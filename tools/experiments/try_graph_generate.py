@@ -1,6 +1,6 @@
 """Experiment: greedy generate_step as plain launches vs a HIP-graph replay (C2 generator)."""
 import os, sys, time, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import nmt_gan_amd as N
