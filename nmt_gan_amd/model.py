@@ -1,16 +1,22 @@
 """Model facade: the generator surface gan_train.py / generate_samples.py call in the reference
 (model.py:18, 203-288, 291-346, 425-435), backed by libnmtgan_hip.so on one MI355X per process.
 
-In scope: get_reward (the hot path), generate_step / generate_and_save (greedy
-sampler, row f-1).  Training entry points raise NotImplementedError.
+Built: get_reward (the hot path), generate_step / generate_and_save (greedy sampler), generate_step_and_update
+(policy-gradient update), init_and_restore / saver.save on TF V2 checkpoint bundles.  The MLE training graph,
+beam search and get_reward_Obinforced are not built: build_train_model only records is_training,
+get_reward_Obinforced raises NotImplementedError.
 
 Differences from the reference that a caller can see:
   * numpy in / numpy out is unchanged; `uniforms=` / `seed=` are keyword-only extensions that
     replace TF's unseeded Philox stream (model.py:239) with injected uniforms u[R, T-1, B, T].
   * residual dropout, which the reference leaves ON during rollouts, is
     neutralised: the path is deterministic given the uniforms.
+  * a call without `uniforms=` / `seed=` draws fresh noise: its seed is `reward_seed_base` plus the number of
+    get_reward calls this Model has served (deterministic, and identical on every rank of a sharded job).
   * with torch.distributed initialised (one process per GPU, RCCL), get_reward shards the sentences
-    across ranks with the reference's split_tensor boundaries and all-gathers the reward rows.
+    across ranks with the reference's split_tensor boundaries and all-gathers the reward rows; with fewer
+    sentences than ranks it shards (sentence, roll) units instead and the per-rollout scores are gathered and
+    summed in roll order on every rank.
 """
 from __future__ import annotations
 
@@ -25,8 +31,8 @@ import torch
 
 from . import _lib
 from ._lib import lib, check, ptr
-from .share_function import (build_rollout_plan, deal_generated_samples, shift_right, split_bounds,
-                             timing_signal)
+from .share_function import (build_rollout_plan, deal_generated_samples, roll_shard_pieces, shift_right,
+                             split_bounds, timing_signal)
 
 INT_TYPE = np.int32
 FLOAT_TYPE = np.float32
@@ -39,6 +45,24 @@ def _cfg_get(cfg, path, default=None):
             return default
         cur = cur.get(k) if isinstance(cur, dict) else getattr(cur, k, None)
     return default if cur is None else cur
+
+
+class _Saver(object):
+    """Stand-in for the `saver` attribute (a tf.train.Saver) the reference's drivers use:
+    `generator.saver.save(generator.sess, path)` (gan_train.py:118, 134), `discriminator.saver.save(
+    discriminator.sess, discriminator.saveto)` (gan_train.py:161), `saver.restore(sess, path)` (model.py:432).
+    `sess` is accepted and ignored; the files are TF V2 checkpoint bundles."""
+
+    def __init__(self, save_fn, restore_fn):
+        self._save_fn, self._restore_fn = save_fn, restore_fn
+
+    def save(self, sess, save_path, global_step=None, **_ignored):
+        path = str(save_path) if global_step is None else "%s-%d" % (save_path, int(global_step))
+        self._save_fn(path)
+        return path
+
+    def restore(self, sess, save_path):
+        self._restore_fn(str(save_path))
 
 
 class Model(object):
@@ -81,6 +105,10 @@ class Model(object):
         self.last_details = None
         self.g_optimizer = 'rmsprop'
         self._W_src, self._train = None, None
+        self.reward_seed_base = 0      # seed of the n-th get_reward call without uniforms=/seed= is base + n
+        self._reward_calls = 0
+        self._gather_bufs = {}
+        self.saver = _Saver(self.save, lambda path: self.init_and_restore(modelFile=path))
 
     # ------------------------------------------------------------------ graph-building surface
     def build_train_model(self):
@@ -456,7 +484,10 @@ class Model(object):
             raise ValueError("disc.max_len != max_len")
         rollnum = int(rollnum)
         if uniforms is None:
-            uniforms = self.make_uniforms(rollnum, T, B, 0 if seed is None else seed)
+            if seed is None:           # fresh noise per call, as tf.multinomial draws it (model.py:239)
+                seed = int(self.reward_seed_base) + self._reward_calls
+            uniforms = self.make_uniforms(rollnum, T, B, seed)
+        self._reward_calls += 1
         u = torch.as_tensor(uniforms)
         if tuple(u.shape) != (rollnum, T - 1, B, T):
             raise ValueError("uniforms must have shape [rollnum, max_len-1, batch, max_len]")
@@ -465,6 +496,10 @@ class Model(object):
         world, rank = 1, 0
         if shard and torch.distributed.is_available() and torch.distributed.is_initialized():
             world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+        if world > 1 and B < world:
+            out = self._reward_roll_sharded(x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, world, rank)
+            torch.cuda.synchronize(self.device)
+            return out.cpu().numpy()
         bounds = split_bounds(B, world)
         b0, b1 = bounds[rank], bounds[rank + 1]
         local = self._reward_local(x[b0:b1], x_pad_T[b0:b1], y[b0:b1], mask[b0:b1], rollnum, disc, T, bias_num, u,
@@ -472,9 +507,45 @@ class Model(object):
         if world == 1:
             out = local
         else:
-            out = gather_rows(local, bounds, self.device)
+            out = gather_rows(local, bounds, self.device, self._gather_bufs)
         torch.cuda.synchronize(self.device)
         return out.cpu().numpy()
+
+    def _reward_roll_sharded(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, world, rank):
+        """Fewer sentences than ranks: the (sentence, roll) units are cut across the ranks (all prefixes of a
+        unit stay on one rank).  A rank scores its pieces - one sentence with a range of rolls each, uniforms
+        addressed by global sentence and roll - and leaves P(real) of every rollout in a [units, T] block
+        (column g-1 = prefix g, last column = P(real) of y_sample itself); one all-gather of the blocks, then
+        every rank runs the reward reduction over all rolls in roll order: the sums are those of the unsharded
+        call.  Replaces the tower split/concat of model.py:248-261 for B < world."""
+        B, R, dev = x.shape[0], rollnum, self.device
+        u0, u1, pieces = roll_shard_pieces(B, R, world, rank)
+        part = torch.zeros((max(u1 - u0, 0), T), dtype=torch.float32, device=dev)
+        for b, r0, r1 in pieces:
+            prep = self.prepare_reward(x[b:b + 1], x_pad_T[b:b + 1], y[b:b + 1], mask[b:b + 1], r1 - r0, disc, T, None, u,
+                                       b_offset=b, B_global=B, r_offset=r0, return_details="scores")
+            prep.launch()
+            plan, d = prep.plan, prep.details
+            rows = torch.arange(r0, r1, device=dev) + (b * R - u0)
+            part[rows, T - 1] = d["p_base"][0]
+            if plan.n_rows > 0:
+                rr = torch.as_tensor(plan.row_r.astype(np.int64), device=dev) + (b * R + r0 - u0)
+                gg = torch.as_tensor(plan.row_g.astype(np.int64), device=dev) - 1
+                part[rr, gg] = d["p_rows"][:plan.n_rows]
+            torch.cuda.synchronize(dev)        # the next piece re-uses the workspace and the score buffers' owner
+        full = gather_rows(part, split_bounds(B * R, world), dev, self._gather_bufs)          # [B*R, T]
+        p = full[:, :T - 1].reshape(B, R, T - 1).permute(0, 2, 1).contiguous()                 # [B, T-1, R]
+        p_base = full[:, T - 1].reshape(B, R)[:, 0].contiguous()
+        lens = (mask != 0).sum(axis=1)
+        first = (np.arange(B)[:, None] * (T - 1) + np.arange(T - 1)[None, :]) * R
+        grp_first = np.where(np.arange(1, T)[None, :] < lens[:, None], first, -1).astype(np.int32)
+        gf = self._dev_i32(grp_first)
+        md = torch.as_tensor(np.ascontiguousarray(mask, dtype=np.float32)).to(dev)
+        rewards = torch.zeros((B, T), dtype=torch.float32, device=dev)
+        check(lib.nmtgan_reward_reduce(ptr(p), ptr(p_base), ptr(gf), ptr(md), B, T, R, 0 if bias_num is None else 1,
+                                       0.0 if bias_num is None else float(bias_num), ptr(rewards), _lib.stream_ptr()),
+              "nmtgan_reward_reduce")
+        return rewards
 
     def _reward_local(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, b_offset, B_global, return_details):
         if x.shape[0] == 0:
@@ -488,13 +559,14 @@ class Model(object):
         return rewards
 
     def prepare_reward(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, b_offset=0, B_global=None,
-                       return_details=False, own_workspace=False, stream=None):
+                       return_details=False, own_workspace=False, stream=None, r_offset=0):
         """Host half of get_reward: build the rollout plan, upload ids/tables, size the workspace.
         Returns a PreparedReward whose launch() only enqueues device work (inputs resident in HBM)."""
         dev = self.device
         x = np.ascontiguousarray(np.asarray(x), dtype=np.int32)
         B, Ls = x.shape
-        plan = build_rollout_plan(mask, rollnum, b_offset=b_offset, B_global=B if B_global is None else B_global)
+        plan = build_rollout_plan(mask, rollnum, b_offset=b_offset, B_global=B if B_global is None else B_global,
+                                  r_offset=r_offset)
         xd = self._dev_i32(x)
         t = {
             "x": xd, "x_pad": (xd == 0).to(torch.uint8).contiguous(), "x_pad_T": self._dev_i32(x_pad_T),
@@ -539,16 +611,17 @@ class Model(object):
             p.aux_stream = self._aux_stream.cuda_stream
             p.aux_gemm_wgs, p.aux_min_rows = int(self.aux_gemm_wgs), int(self.aux_min_rows)
         details = None
-        if return_details:
+        if return_details:             # "scores": only P(real) per rollout and of y_sample
             details = {
                 "plan": plan,
-                "rollouts": torch.zeros((max(plan.n_rows, 1), T), dtype=torch.int32, device=dev),
                 "p_rows": torch.zeros(max(plan.n_rows, 1), dtype=torch.float32, device=dev),
                 "p_base": torch.zeros(B, dtype=torch.float32, device=dev),
-                "prefix_logits": torch.zeros((B, T, self.dst_vocab_size), dtype=torch.float32, device=dev),
             }
-            p.rollouts, p.p_rows = ptr(details["rollouts"]), ptr(details["p_rows"])
-            p.p_base, p.prefix_logits = ptr(details["p_base"]), ptr(details["prefix_logits"])
+            p.p_rows, p.p_base = ptr(details["p_rows"]), ptr(details["p_base"])
+            if return_details != "scores":
+                details["rollouts"] = torch.zeros((max(plan.n_rows, 1), T), dtype=torch.int32, device=dev)
+                details["prefix_logits"] = torch.zeros((B, T, self.dst_vocab_size), dtype=torch.float32, device=dev)
+                p.rollouts, p.prefix_logits = ptr(details["rollouts"]), ptr(details["prefix_logits"])
         g, dsc = self.c_struct, disc.c_struct
         need = lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(dsc), C.byref(p))
         if own_workspace:              # several prepared calls alive at once (sub-batches on their own streams)
@@ -619,19 +692,28 @@ class PreparedReward(object):
         return self.tensors["rewards"]
 
 
-def gather_rows(local: torch.Tensor, bounds, device) -> torch.Tensor:
+def gather_rows(local: torch.Tensor, bounds, device, cache=None) -> torch.Tensor:
     """All-gather of per-rank reward rows [B_i, T] -> [B, T] (the implicit tf.concat of the tower
     outputs, model.py:261 / cnn_discriminator.py:558).  Shards may be uneven (split_tensor uses
-    float linspace boundaries), so rows are padded to the largest shard for the collective."""
+    float linspace boundaries), so rows are padded to the largest shard for the collective.
+    `cache` (a dict the caller keeps) holds the send/receive buffers between calls, so a steady-state
+    call allocates only its result.  gloo gets host tensors (synchronous copies), RCCL device tensors."""
     import torch.distributed as dist
     world = dist.get_world_size()
     sizes = [bounds[i + 1] - bounds[i] for i in range(world)]
     mx = max(max(sizes), 1)
     T = local.shape[1]
-    backend = dist.get_backend()
-    work_dev = device if backend == "nccl" else torch.device("cpu")
-    padded = torch.zeros((mx, T), dtype=torch.float32, device=work_dev)
-    padded[: local.shape[0]] = local.to(work_dev)
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded)
-    return torch.cat([parts[i][: sizes[i]] for i in range(world)], dim=0).to(device)
+    work_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+    key = (world, mx, T, str(work_dev))
+    bufs = cache.get(key) if cache is not None else None
+    if bufs is None:
+        bufs = (torch.zeros((mx, T), dtype=torch.float32, device=work_dev),
+                torch.zeros((world, mx, T), dtype=torch.float32, device=work_dev))
+        if cache is not None:
+            cache[key] = bufs
+    padded, recv = bufs
+    padded[: local.shape[0]].copy_(local)
+    dist.all_gather([recv[i] for i in range(world)], padded)
+    if all(n == mx for n in sizes):
+        return recv.reshape(world * mx, T).to(device)
+    return torch.cat([recv[i, : sizes[i]] for i in range(world)], dim=0).to(device)

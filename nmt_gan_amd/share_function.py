@@ -10,16 +10,46 @@ import numpy as np
 PAD_ID, UNK_ID, BOS_ID, EOS_ID = 0, 1, 2, 3      # reference utils.py:39, 269, 287
 
 
+def _first_eos_cut(y_sample, dicts, width):
+    """Rows of `y_sample` (a 2-D array or a list of id sequences of any lengths) cut before their first </S>
+    and laid into [n, width]; the id of </S> is `dicts.get('</S>')` exactly as in the reference - a map
+    without that key therefore cuts nothing - and id 3 when no map is given (keyword-free extension)."""
+    eos = EOS_ID if dicts is None else dicts.get("</S>")
+    n = len(y_sample)
+    y = np.zeros((n, width), dtype=np.int32)
+    mask = np.zeros((n, width), dtype=np.float32)
+    if isinstance(y_sample, np.ndarray) and y_sample.ndim == 2 and y_sample.shape[1] <= width:
+        L = y_sample.shape[1]
+        hit = (y_sample == eos) if eos is not None else np.zeros(y_sample.shape, bool)
+        first = np.where(hit.any(axis=1), hit.argmax(axis=1), L)
+        keep = np.arange(L)[None, :] < first[:, None]
+        y[:, :L] = np.where(keep, y_sample, 0)
+        mask[:, :L] = keep
+        return y, mask
+    for i, s in enumerate(y_sample):
+        s = np.asarray(s).reshape(-1)
+        hit = np.flatnonzero(s == eos) if eos is not None else ()
+        first = int(hit[0]) if len(hit) else len(s)
+        if first > width:
+            raise ValueError("sentence %d has %d tokens before </S>, more than %d columns" % (i, first, width))
+        y[i, :first] = s[:first]
+        mask[i, :first] = 1.0
+    return y, mask
+
+
 def deal_generated_samples(y_sample, dicts=None):
-    """Zero every position from the first </S> on; mask = 1 before it.
-    Mirrors share_function.py:269-289 (`dicts` is the dst word->id map; </S> defaults to id 3)."""
-    eos = EOS_ID if dicts is None else dicts.get("</S>", EOS_ID)
-    y_sample = np.asarray(y_sample)
-    n, L = y_sample.shape
-    hit = y_sample == eos
-    first = np.where(hit.any(axis=1), hit.argmax(axis=1), L)
-    keep = np.arange(L)[None, :] < first[:, None]
-    return np.where(keep, y_sample, 0).astype(np.int32), keep.astype(np.float32)
+    """Zero every position from the first </S> on; mask = 1 before it (</S> not included).
+    Mirrors share_function.py:269-289; the output is as wide as the longest input row."""
+    width = y_sample.shape[1] if isinstance(y_sample, np.ndarray) and y_sample.ndim == 2 else \
+        max([len(s) for s in y_sample] or [0])
+    return _first_eos_cut(y_sample, dicts, width)
+
+
+def deal_generated_samples_to_maxlen(y_sample, dicts, maxlen):
+    """Same cut, laid into [n, maxlen] (share_function.py:291-309; gan_train.py:123 prepares the ground-truth
+    batch of the teacher-forcing update with it).  Like the reference's slice assignment it raises when a
+    sentence keeps more than maxlen tokens."""
+    return _first_eos_cut(y_sample, dicts, int(maxlen))
 
 
 def extend_sentence_to_maxlen(seqs, maxlen=50):
@@ -32,6 +62,20 @@ def extend_sentence_to_maxlen(seqs, maxlen=50):
             raise ValueError("sentence %d has length %d > maxlen %d" % (i, len(s), maxlen))
         x[i, :len(s)] = s
     return x
+
+
+class FlushFile(object):
+    """stdout wrapper that flushes after every write (share_function.py:75-84; gan_train.py:167 installs it)."""
+
+    def __init__(self, f):
+        self.f = f
+
+    def write(self, x):
+        self.f.write(x)
+        self.f.flush()
+
+    def flush(self):
+        self.f.flush()
 
 
 def prepare_gan_dis_data(train_data_source, train_data_target, gan_dis_source_data, gan_dis_positive_data,
@@ -92,6 +136,22 @@ def shift_right(y, pad=BOS_ID):
     return np.concatenate([np.full_like(y[:, :1], pad), y[:, :-1]], axis=1)
 
 
+def roll_shard_pieces(B, rollnum, world, rank):
+    """Roll-level spill of the (sentence, roll) sharding for B < world: the B*rollnum (b, r) units, sentence-major,
+    are cut with the split_tensor boundaries; returns (u0, u1, [(b, r0, r1), ..]) - this rank's unit range and the
+    (sentence, roll range) pieces inside it.  All prefixes g of a (b, r) stay on one rank."""
+    bounds = split_bounds(B * rollnum, world)
+    u0, u1 = bounds[rank], bounds[rank + 1]
+    pieces = []
+    b = u0 // rollnum if rollnum else 0
+    while b * rollnum < u1 and u0 < u1:
+        r0, r1 = max(u0, b * rollnum) - b * rollnum, min(u1, (b + 1) * rollnum) - b * rollnum
+        if r1 > r0:
+            pieces.append((b, r0, r1))
+        b += 1
+    return u0, u1, pieces
+
+
 def split_bounds(batch_size, n):
     """Shard boundaries of split_tensor (model.py:742-753): int(linspace(0, B, n+1))."""
     return [int(v) for v in np.linspace(0.0, float(batch_size), n + 1).astype(np.float32).astype(np.int32)]
@@ -126,11 +186,12 @@ class RolloutPlan:
         return int(self.live.shape[0] - 1)
 
 
-def build_rollout_plan(y_sample_mask, rollnum, b_offset=0, B_global=None) -> RolloutPlan:
+def build_rollout_plan(y_sample_mask, rollnum, b_offset=0, B_global=None, r_offset=0) -> RolloutPlan:
     """Rows (b, r, g) for 1 <= g < len_b: for g >= len_b the masked rollout equals y_sample[b]
     (model.py:307), so those are scored once through p_base.  Row (b, r, g) samples
     positions g .. len_b-1: the first from the shared prefix logits, then len_b-1-g private steps.
-    Uniforms are addressed by GLOBAL sentence index so any sharding draws identical tokens."""
+    Uniforms are addressed by GLOBAL sentence index (local b + b_offset) and GLOBAL roll index (local r +
+    r_offset, for a shard that holds only some rolls of a sentence) so any sharding draws identical tokens."""
     mask = np.asarray(y_sample_mask)
     B, T = mask.shape
     lens = (mask != 0).sum(axis=1).astype(np.int64)
@@ -160,7 +221,7 @@ def build_rollout_plan(y_sample_mask, rollnum, b_offset=0, B_global=None) -> Rol
     live[0] = row_b.shape[0]
     step_off = np.zeros(n_steps + 1, np.int64)
     step_off[1:] = np.cumsum(live[1:].astype(np.int64))
-    row_uoff = ((row_r * (T - 1) + (row_g - 1)) * B_global + (row_b + b_offset)) * T + row_g
+    row_uoff = (((row_r + int(r_offset)) * (T - 1) + (row_g - 1)) * B_global + (row_b + b_offset)) * T + row_g
     slots, table, tlive = group_slot_table(grp_first, lens, rollnum, live)
     return RolloutPlan(grp_slots=slots, grp_table=table, grp_live=tlive,
                        B=B, T=T, rollnum=rollnum, lens=lens, row_b=row_b.astype(np.int32),

@@ -211,6 +211,20 @@ def test_rollout_plan_invariants():
     assert big.grp_slots == 0 and big.grp_table.shape[0] == 0
 
 
+def test_roll_shard_pieces_cover_every_unit_once():
+    """(sentence, roll) units for B < world: every unit on exactly one rank, contiguous, sentence-major."""
+    from nmt_gan_amd.share_function import roll_shard_pieces
+    for B, R, world in ((5, 16, 8), (1, 4, 2), (3, 4, 8), (1, 2, 8), (7, 3, 8)):
+        seen = []
+        for rank in range(world):
+            u0, u1, pieces = roll_shard_pieces(B, R, world, rank)
+            units = [b * R + r for b, r0, r1 in pieces for r in range(r0, r1)]
+            assert units == list(range(u0, u1))
+            assert all(0 <= r0 < r1 <= R and 0 <= b < B for b, r0, r1 in pieces)
+            seen += units
+        assert seen == list(range(B * R))
+
+
 _GLOO_WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
@@ -233,6 +247,24 @@ part = build_rollout_plan(mask[bounds[rank]:bounds[rank + 1]], R, b_offset=bound
 key = lambda p, off: {(int(b) + off, int(r), int(g)): int(u) for b, r, g, u in zip(p.row_b, p.row_r, p.row_g, p.row_uoff)}
 kw, kp = key(whole, 0), key(part, bounds[rank])
 assert all(kw[k] == v for k, v in kp.items()) and len(kp) == part.n_rows
+# roll-level spill (fewer sentences than ranks): (sentence, roll) units, uniforms by global (b, r)
+from nmt_gan_amd.share_function import roll_shard_pieces
+B1, R1 = 1, 5
+mask1 = np.ones((B1, T), np.float32)
+whole1 = key(build_rollout_plan(mask1, R1), 0)
+u0, u1, pieces = roll_shard_pieces(B1, R1, 2, rank)
+assert (u0, u1) == ((0, 2) if rank == 0 else (2, 5)) and pieces == [(0, u0, u1)]
+got = {}
+for b, r0, r1 in pieces:
+    pp = build_rollout_plan(mask1[b:b + 1], r1 - r0, b_offset=b, B_global=B1, r_offset=r0)
+    got.update({(int(bb) + b, int(r) + r0, int(g)): int(uu) for bb, r, g, uu in zip(pp.row_b, pp.row_r, pp.row_g, pp.row_uoff)})
+assert all(whole1[k] == v for k, v in got.items()) and len(got) == (u1 - u0) * (T - 1)
+cache = {}
+blk = torch.full((u1 - u0, T), float(rank + 1))
+for _ in range(2):                                 # second call re-uses the cached send/receive buffers
+    allp = gather_rows(blk, split_bounds(B1 * R1, 2), torch.device("cpu"), cache)
+    assert allp.shape == (5, T) and allp[:2].eq(1).all() and allp[2:].eq(2).all()
+assert len(cache) == 1
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
