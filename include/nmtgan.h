@@ -18,8 +18,10 @@
  *    pool per device for the two-stream schedule: calls from different threads / on different streams do not
  *    interfere, as long as concurrent calls use different workspaces.
  *  - "op dtype" = the MFMA operand / KV-cache / activation-copy element type of a packed model:
- *    NMTGAN_BF16 (bf16 operands, fp32 accumulate; the throughput tier) or NMTGAN_F32 (exact fp32
- *    MFMA; the 1e-5 parity tier).  Residual stream, LayerNorm, softmax, CDF are fp32/fp64 always.
+ *    NMTGAN_F16 (IEEE half operands, fp32 accumulate: the throughput tier - 2^-12 operand rounding, values
+ *    saturate at +-65504), NMTGAN_BF16 (bf16 operands at the same MFMA rate, 2^-9 operand rounding, fp32 range)
+ *    or NMTGAN_F32 (exact fp32 MFMA; the 1e-5 parity tier).  Residual stream, LayerNorm, softmax, CDF are
+ *    fp32/fp64 always.
  *  - weight matrices are stored TRANSPOSED, Wt[N][K] K-contiguous (TF stores kernel[K][N]); the
  *    Python facade repacks once at load time.
  */
@@ -36,6 +38,7 @@ extern "C" {
 #define NMTGAN_VERSION 1
 #define NMTGAN_BF16 0
 #define NMTGAN_F32 1
+#define NMTGAN_F16 2
 #define NMTGAN_MAX_BLOCKS 16
 #define NMTGAN_MAX_WIDTHS 32
 
@@ -150,7 +153,7 @@ typedef struct {
 int nmtgan_attn_rows(const nmtgan_attn_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Group attention (bf16 only): the rows_per_group (<= 32) consecutive query rows of a group share one
+ * Group attention (16-bit op dtypes only): the rows_per_group (<= 32) consecutive query rows of a group share one
  * block of keys (the rollouts of one (sentence, prefix) pair share the teacher-forced prefix and the
  * encoder memory), so K/V are loaded once per group and the products run on MFMA.  Same math as
  * nmtgan_attn_rows segment 1 (common_attention.py:294-331).  k[nblk][len][d] row-major,
@@ -160,7 +163,7 @@ int nmtgan_attn_rows(const nmtgan_attn_args* a, void* stream);
  * fp32 [M][d], m_part/l_part [M][heads]) that nmtgan_attn_rows continues over private keys.
  */
 typedef struct {
-  const void* q; int M, d, heads, rows_per_group;   /* q fp32, or bf16 when q_bf16 != 0 */
+  const void* q; int M, d, heads, rows_per_group;   /* q fp32, or kv_dtype when q_bf16 != 0 */
   const void* k; const void* vt; int len, len_padded;
   const int32_t* row_blk; const int32_t* row_cnt; const uint8_t* mask;
   void* out;
@@ -172,9 +175,10 @@ typedef struct {
    * served when 0 <= row0 < M, its rows are row0 .. row0+rows_per_group-1, its key count is cnt (len when
    * row_cnt is NULL).  row_blk / row_cnt are then only used as "counts present" flags. */
   const int32_t* slot_table; int slots; int n_entries;
+  int kv_dtype;              /* NMTGAN_BF16 (0) or NMTGAN_F16: element type of k, vt, out and of q when q_bf16 != 0 */
 } nmtgan_attn_group_args;
 int nmtgan_attn_group(const nmtgan_attn_group_args* a, void* stream);
-/* v[nblk*len][d] bf16 -> vt[nblk][d][len_padded] bf16, zero padded */
+/* v[nblk*len][d] -> vt[nblk][d][len_padded], 16-bit elements (bf16 or fp16), zero padded */
 int nmtgan_transpose_v(const void* v, void* vt, int nblk, int len, int len_padded, int d, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NMTGAN_LIB") or os.path.join(_HERE, "libnmtgan_hip.so")   # NMTGAN_LIB: another build of the same ABI
 
-NMTGAN_BF16, NMTGAN_F32 = 0, 1
+NMTGAN_BF16, NMTGAN_F32, NMTGAN_F16 = 0, 1, 2
 EPI_LINEAR, EPI_CONVMAX = 0, 1
 MAX_BLOCKS, MAX_WIDTHS = 16, 32
 
@@ -51,7 +51,7 @@ class AttnGroupArgs(C.Structure):
                 ("k", vp), ("vt", vp), ("len", i32), ("len_padded", i32),
                 ("row_blk", vp), ("row_cnt", vp), ("mask", vp), ("out", vp),
                 ("o_part", vp), ("m_part", vp), ("l_part", vp), ("q_bf16", i32),
-                ("slot_table", vp), ("slots", i32), ("n_entries", i32)]
+                ("slot_table", vp), ("slots", i32), ("n_entries", i32), ("kv_dtype", i32)]
 
 
 class SampleArgs(C.Structure):
@@ -177,6 +177,17 @@ def _load():
 
 
 lib = _load()
+
+
+def op_dtype_of(precision: str):
+    """(torch dtype, NMTGAN_* code) of the MFMA operand type of a precision tier: 'fp16' (IEEE half operands, the
+    throughput tier), 'bf16' (same rate, 8x coarser operand rounding, fp32 range) or 'fp32' (exact, the parity tier)."""
+    import torch
+    table = {"fp16": (torch.float16, NMTGAN_F16), "bf16": (torch.bfloat16, NMTGAN_BF16),
+             "fp32": (torch.float32, NMTGAN_F32)}
+    if precision not in table:
+        raise ValueError("precision must be 'fp16', 'bf16' or 'fp32'")
+    return table[precision]
 
 
 def check(rc: int, what: str = "nmtgan"):

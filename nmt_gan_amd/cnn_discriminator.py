@@ -20,12 +20,7 @@ from ._lib import lib, check, ptr
 BN_EPS = 1e-3          # tf.contrib.layers.batch_norm default epsilon (cnn_discriminator.py:22-33)
 
 
-def _op_torch_dtype(precision: str):
-    if precision == "bf16":
-        return torch.bfloat16, _lib.NMTGAN_BF16
-    if precision == "fp32":
-        return torch.float32, _lib.NMTGAN_F32
-    raise ValueError("precision must be 'bf16' or 'fp32'")
+_op_torch_dtype = _lib.op_dtype_of
 
 
 class DisCNN(object):

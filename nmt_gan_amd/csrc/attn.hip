@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
   VecIO<KT, EPL>::store(reinterpret_cast<KT*>(p.out) + (int64_t)row * d + lane * EPL, o);
 }
 
-// ------------------------------------------------------------------------------------------ bf16 fast path
-// Same row-per-wave algorithm for bf16 caches with d = 512 / 1024 (the rollout step's private-suffix pass,
+// ------------------------------------------------------------------------------------------ 16-bit fast path
+// Same row-per-wave algorithm for bf16 / fp16 caches with d = 512 / 1024 (the rollout step's private-suffix pass,
 // 278 GB of K/V per C2 get_reward), tuned for bytes in flight:
 //  - K/V stay packed (16 B per lane and vector) and the NEXT batch of KB keys is requested before the
 //    current one is consumed, so 2*KB*2 vector loads per wave are in flight across the softmax chain;
@@ -135,8 +135,8 @@ __device__ __forceinline__ float head_sum(float v, int lph) {   // sum over the 
   return v;
 }
 
-template <int EPL, int KB, typename QT>
-__global__ __launch_bounds__(256) void attn_rows_bf16_kernel(AttnParams p) {
+template <typename KT, int EPL, int KB, typename QT>
+__global__ __launch_bounds__(256) void attn_rows_16_kernel(AttnParams p) {
   constexpr int NV = EPL / 8;                      // 16-byte vectors per lane and key
   constexpr float LOG2E = 1.44269504088896341f;
   const int lane = threadIdx.x & 63;
@@ -149,10 +149,10 @@ __global__ __launch_bounds__(256) void attn_rows_bf16_kernel(AttnParams p) {
   if (p.k1) cnt1 = p.seg1_cnt ? p.seg1_cnt[row] : (p.causal ? row % p.rows_per_blk + 1 : p.len1);
   cnt1 = __builtin_amdgcn_readfirstlane(cnt1);
   const int n_total = cnt1 + p.n_steps2;
-  const bf16_t* k1 = reinterpret_cast<const bf16_t*>(p.k1) + ((int64_t)blk * p.len1) * d + lane * EPL;
-  const bf16_t* v1 = reinterpret_cast<const bf16_t*>(p.v1) + ((int64_t)blk * p.len1) * d + lane * EPL;
-  const bf16_t* k2 = reinterpret_cast<const bf16_t*>(p.k2) + (int64_t)row * d + lane * EPL;
-  const bf16_t* v2 = reinterpret_cast<const bf16_t*>(p.v2) + (int64_t)row * d + lane * EPL;
+  const KT* k1 = reinterpret_cast<const KT*>(p.k1) + ((int64_t)blk * p.len1) * d + lane * EPL;
+  const KT* v1 = reinterpret_cast<const KT*>(p.v1) + ((int64_t)blk * p.len1) * d + lane * EPL;
+  const KT* k2 = reinterpret_cast<const KT*>(p.k2) + (int64_t)row * d + lane * EPL;
+  const KT* v2 = reinterpret_cast<const KT*>(p.v2) + (int64_t)row * d + lane * EPL;
   const uint8_t* mk = p.mask1 ? p.mask1 + (int64_t)blk * p.len1 : nullptr;
 
   float q[EPL];
@@ -200,12 +200,7 @@ __global__ __launch_bounds__(256) void attn_rows_bf16_kernel(AttnParams p) {
   };
   auto unpack = [](const uint4 (&r)[NV], float (&f)[EPL]) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      f[8 * i + 0] = __uint_as_float(r[i].x << 16); f[8 * i + 1] = __uint_as_float(r[i].x & 0xffff0000u);
-      f[8 * i + 2] = __uint_as_float(r[i].y << 16); f[8 * i + 3] = __uint_as_float(r[i].y & 0xffff0000u);
-      f[8 * i + 4] = __uint_as_float(r[i].z << 16); f[8 * i + 5] = __uint_as_float(r[i].z & 0xffff0000u);
-      f[8 * i + 6] = __uint_as_float(r[i].w << 16); f[8 * i + 7] = __uint_as_float(r[i].w & 0xffff0000u);
-    }
+    for (int i = 0; i < NV; ++i) unpack8<KT>(r[i], f + 8 * i);
   };
   auto consume = [&](const uint4 (&kr)[KB][NV], const uint4 (&vr)[KB][NV], unsigned okm) {
     float s[KB];
@@ -253,7 +248,7 @@ __global__ __launch_bounds__(256) void attn_rows_bf16_kernel(AttnParams p) {
   const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
   for (int e = 0; e < EPL; ++e) o[e] *= inv;
-  VecIO<bf16_t, EPL>::store(reinterpret_cast<bf16_t*>(p.out) + (int64_t)row * d + lane * EPL, o);
+  VecIO<KT, EPL>::store(reinterpret_cast<KT*>(p.out) + (int64_t)row * d + lane * EPL, o);
 }
 
 template <typename KT, typename QT>
@@ -262,8 +257,8 @@ static int launch_attn_t(const AttnParams& p, hipStream_t st) {
   dim3 grid((p.M + 3) / 4), block(256);
   if constexpr (sizeof(KT) == 2) {
     static const bool fast = [] { const char* e = getenv("NMTGAN_ATTN_FAST"); return !e || atoi(e) != 0; }();
-    if (fast && epl == 8) { hipLaunchKernelGGL((attn_rows_bf16_kernel<8, 4, QT>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
-    if (fast && epl == 16) { hipLaunchKernelGGL((attn_rows_bf16_kernel<16, 2, QT>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
+    if (fast && epl == 8) { hipLaunchKernelGGL((attn_rows_16_kernel<KT, 8, 4, QT>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
+    if (fast && epl == 16) { hipLaunchKernelGGL((attn_rows_16_kernel<KT, 16, 2, QT>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
   }
   switch (epl) {
     case 1: hipLaunchKernelGGL((attn_rows_kernel<KT, 1, 4, QT>), grid, block, 0, st, p); break;
@@ -296,6 +291,7 @@ int launch_attn_rows(const nmtgan_attn_args* a, hipStream_t st) {
   AttnParams p{a->q, a->M, a->d, a->heads, a->k1, a->v1, a->len1, a->seg1_blk, a->seg1_cnt, a->rows_per_blk,
                a->causal, a->mask1, a->k2, a->v2, a->step_off, a->n_steps2, a->out, a->o_init, a->m_init, a->l_init};
   if (a->kv_dtype == NMTGAN_BF16) return a->q_op_dtype ? launch_attn_t<bf16_t, bf16_t>(p, st) : launch_attn_t<bf16_t, float>(p, st);
+  if (a->kv_dtype == NMTGAN_F16) return a->q_op_dtype ? launch_attn_t<f16_t, f16_t>(p, st) : launch_attn_t<f16_t, float>(p, st);
   if (a->kv_dtype == NMTGAN_F32) return launch_attn_t<float, float>(p, st);
   NMTGAN_FAIL(-2, "attn: bad kv_dtype %d", a->kv_dtype);
 }

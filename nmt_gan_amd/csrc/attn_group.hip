@@ -1,4 +1,4 @@
-// Group attention for gfx950 (bf16 tier): the R rollouts of one (sentence, prefix) group share their
+// Group attention for gfx950 (16-bit tiers: bf16 or fp16 operands): the R rollouts of one (sentence, prefix) group share their
 // keys - the teacher-forced prefix of the sentence, or the encoder memory - so one workgroup loads
 // every K/V element ONCE for all R query rows and does the arithmetic on the matrix cores.
 //
@@ -20,35 +20,28 @@
 namespace nmtgan {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 struct GroupAttnParams {
-  const void* q;               // [M][d] fp32 or bf16 (q_bf16), already scaled
+  const void* q;               // [M][d] fp32 or the 16-bit op dtype (q_bf16), already scaled
   int M, d, heads, R;          // R rows per group (<= 32)
-  const bf16_t* k;             // [nblk][L][d]
-  const bf16_t* vt;            // [nblk][d][Lp]
+  const void* k;               // [nblk][L][d]       16-bit op dtype (bf16 or fp16)
+  const void* vt;              // [nblk][d][Lp]
   int L, Lp;
   const int32_t* row_blk;      // [M] block of a row (read at the group's first row)
   const int32_t* row_cnt;      // [M] keys of a row, or NULL -> L
   const uint8_t* mask;         // [nblk][L] or NULL
-  bf16_t* out;                 // [M][d] normalised output (final mode) or NULL
+  void* out;                   // [M][d] normalised output in the op dtype (final mode) or NULL
   float* o_part; float* m_part; float* l_part;   // partial mode: [M][d], [M][heads], [M][heads]
   // slot form: workgroup e serves `slots` groups of ONE block of keys, table row e =
   // [blk, 0, row0[slots], cnt[slots]]; a slot is live when 0 <= row0 < M (its R rows are row0 .. row0+R-1)
   const int32_t* slot_table; int slots;
 };
 
-__device__ __forceinline__ bf16x8 pack8(const float* v) {
-  bf16x8 r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
-  return r;
-}
 
 // One wave per (group, head); a workgroup = 4 heads of one group (grid.y = heads / 4).  The kernel is
 // latency-bound (two 32-key tiles per head at T = Ls = 50, ~30 MFMAs), so every global load of a 64-key
 // pair - q, both K tiles, both V^T tiles, the padding mask - is issued before the first MFMA.
-template <int DK, bool QB>
+template <typename KT, int DK, bool QB>
 __global__ __launch_bounds__(256, (DK <= 64 ? 3 : 1)) void attn_group_kernel(GroupAttnParams p) {
   constexpr int KS = DK / 16;      // k-steps of the QK^T product
   constexpr int DT = DK / 32;      // 32-row tiles of O^T
@@ -83,13 +76,13 @@ __global__ __launch_bounds__(256, (DK <= 64 ? 3 : 1)) void attn_group_kernel(Gro
   const int d = p.d;
   const uint8_t* mk = p.mask ? p.mask + (int64_t)blk * p.L : nullptr;
 
-  bf16x8 qf[KS];
+  uint4 qf[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     if constexpr (QB) {
       uint4 t = make_uint4(0, 0, 0, 0);
-      if (row_ok) t = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.q) + (int64_t)row * d + head * DK + 16 * s + 8 * h2);
-      qf[s] = __builtin_bit_cast(bf16x8, t);
+      if (row_ok) t = *reinterpret_cast<const uint4*>(reinterpret_cast<const KT*>(p.q) + (int64_t)row * d + head * DK + 16 * s + 8 * h2);
+      qf[s] = t;
     } else {
       float t[8];
       if (row_ok) VecIO<float, 8>::load(reinterpret_cast<const float*>(p.q) + (int64_t)row * d + head * DK + 16 * s + 8 * h2, t);
@@ -97,7 +90,7 @@ __global__ __launch_bounds__(256, (DK <= 64 ? 3 : 1)) void attn_group_kernel(Gro
 #pragma unroll
         for (int i = 0; i < 8; ++i) t[i] = 0.f;
       }
-      qf[s] = pack8(t);
+      qf[s] = pack8u<KT>(t);
     }
   }
   f32x16 o[DT];
@@ -106,8 +99,8 @@ __global__ __launch_bounds__(256, (DK <= 64 ? 3 : 1)) void attn_group_kernel(Gro
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
   float m = -INFINITY, l = 0.f;
-  const bf16_t* Kb = p.k + (int64_t)blk * p.L * d + head * DK + 8 * h2;
-  const bf16_t* Vb = p.vt + ((int64_t)blk * d + head * DK + n) * p.Lp + 4 * h2;
+  const KT* Kb = reinterpret_cast<const KT*>(p.k) + (int64_t)blk * p.L * d + head * DK + 8 * h2;
+  const KT* Vb = reinterpret_cast<const KT*>(p.vt) + ((int64_t)blk * d + head * DK + n) * p.Lp + 4 * h2;
 
   auto load_k = [&](int k0, uint4 (&kr)[KS]) {
     const int keyc = min(k0 + n, p.L - 1);
@@ -120,7 +113,7 @@ __global__ __launch_bounds__(256, (DK <= 64 ? 3 : 1)) void attn_group_kernel(Gro
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         // element j of half h2 must be key 16s + 8(j>>2) + 4*h2 + (j&3) (operand k-order of the acc tile)
-        const bf16_t* vp = Vb + (int64_t)(32 * t) * p.Lp + k0 + 16 * s;
+        const KT* vp = Vb + (int64_t)(32 * t) * p.Lp + k0 + 16 * s;
         const uint2 lo = *reinterpret_cast<const uint2*>(vp);
         const uint2 hi = *reinterpret_cast<const uint2*>(vp + 8);
         vr[t][s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -133,7 +126,7 @@ __global__ __launch_bounds__(256, (DK <= 64 ? 3 : 1)) void attn_group_kernel(Gro
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kr[s]), qf[s], sacc, 0, 0, 0);
+      sacc = mfma16<KT>(kr[s], qf[s], sacc);
     float sv[16];
     float mx = -INFINITY;
 #pragma unroll
@@ -158,14 +151,14 @@ __global__ __launch_bounds__(256, (DK <= 64 ? 3 : 1)) void attn_group_kernel(Gro
     ls += __shfl_xor(ls, 32, 64);
     l = l * alpha + ls;
     m = m_new;
-    bf16x8 pf[2] = {pack8(pv), pack8(pv + 8)};
+    const uint4 pf[2] = {pack8u<KT>(pv), pack8u<KT>(pv + 8)};
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vr[t][s]), pf[s], o[t], 0, 0, 0);
+        o[t] = mfma16<KT>(vr[t][s], pf[s], o[t]);
     }
   };
 
@@ -194,7 +187,7 @@ __global__ __launch_bounds__(256, (DK <= 64 ? 3 : 1)) void attn_group_kernel(Gro
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float v4[4] = {o[t][4 * c] * inv, o[t][4 * c + 1] * inv, o[t][4 * c + 2] * inv, o[t][4 * c + 3] * inv};
-        VecIO<bf16_t, 4>::store(p.out + (int64_t)row * d + head * DK + 32 * t + 8 * c + 4 * h2, v4);
+        VecIO<KT, 4>::store(reinterpret_cast<KT*>(p.out) + (int64_t)row * d + head * DK + 32 * t + 8 * c + 4 * h2, v4);
       }
   } else {
 #pragma unroll
@@ -212,21 +205,21 @@ __global__ __launch_bounds__(256, (DK <= 64 ? 3 : 1)) void attn_group_kernel(Gro
 }
 
 // V [nblk*L][d] -> V^T [nblk][d][Lp], zero padded to Lp (multiple of 32, >= L)
-__global__ void transpose_v_kernel(const bf16_t* v, bf16_t* vt, int nblk, int L, int Lp, int d) {
+__global__ void transpose_v_kernel(const unsigned short* v, unsigned short* vt, int nblk, int L, int Lp, int d) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)nblk * d * Lp) return;
   const int t = (int)(i % Lp);
   const int c = (int)((i / Lp) % d);
   const int b = (int)(i / ((int64_t)Lp * d));
-  vt[i] = t < L ? v[((int64_t)b * L + t) * d + c] : (bf16_t)0;
+  vt[i] = t < L ? v[((int64_t)b * L + t) * d + c] : (unsigned short)0;      // raw 16-bit elements: bf16 or fp16
 }
 
 int launch_transpose_v(const void* v, void* vt, int nblk, int L, int Lp, int d, hipStream_t st) {
   prof::Scope prof_scope(prof::OTHER, st);
   NMTGAN_REQUIRE(v && vt && nblk > 0 && L > 0 && Lp >= L && Lp % 32 == 0 && d > 0, "transpose_v: bad arguments");
   const int64_t n = (int64_t)nblk * d * Lp;
-  hipLaunchKernelGGL(transpose_v_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)v,
-                     (bf16_t*)vt, nblk, L, Lp, d);
+  hipLaunchKernelGGL(transpose_v_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const unsigned short*)v,
+                     (unsigned short*)vt, nblk, L, Lp, d);
   NMTGAN_CHECK_LAUNCH("transpose_v");
   return 0;
 }
@@ -245,15 +238,20 @@ int launch_attn_group(const nmtgan_attn_group_args* a, hipStream_t st) {
   NMTGAN_REQUIRE(a->len > 0 && a->len_padded >= a->len && a->len_padded % 32 == 0, "attn_group: bad key lengths");
   NMTGAN_REQUIRE((a->out != nullptr) != (a->o_part != nullptr), "attn_group: exactly one of out / o_part");
   NMTGAN_REQUIRE(a->out || (a->m_part && a->l_part), "attn_group: partial mode needs m_part and l_part");
-  GroupAttnParams p{a->q, a->M, a->d, a->heads, a->rows_per_group, (const bf16_t*)a->k, (const bf16_t*)a->vt, a->len,
-                    a->len_padded, a->row_blk, a->row_cnt, a->mask, (bf16_t*)a->out, a->o_part, a->m_part, a->l_part,
+  GroupAttnParams p{a->q, a->M, a->d, a->heads, a->rows_per_group, a->k, a->vt, a->len,
+                    a->len_padded, a->row_blk, a->row_cnt, a->mask, a->out, a->o_part, a->m_part, a->l_part,
                     a->slot_table, a->slots};
+  NMTGAN_REQUIRE(a->kv_dtype == NMTGAN_BF16 || a->kv_dtype == NMTGAN_F16, "attn_group: kv_dtype must be a 16-bit op dtype");
+  const bool half = a->kv_dtype == NMTGAN_F16;
   dim3 grid(a->slot_table ? a->n_entries : a->M / a->rows_per_group, (a->heads + 3) / 4), block(256);
   const bool qb = a->q_bf16 != 0;
   NMTGAN_REQUIRE(!qb || ((uintptr_t)a->q % 16 == 0 && a->d % 8 == 0), "attn_group: bf16 q must be 16-byte aligned");
-#define NMTGAN_GROUP(DK)                                                                      \
-  if (qb) hipLaunchKernelGGL((attn_group_kernel<DK, true>), grid, block, 0, st, p);           \
-  else hipLaunchKernelGGL((attn_group_kernel<DK, false>), grid, block, 0, st, p)
+#define NMTGAN_GROUP(DK)                                                                              \
+  if (half) {                                                                                         \
+    if (qb) hipLaunchKernelGGL((attn_group_kernel<f16_t, DK, true>), grid, block, 0, st, p);          \
+    else hipLaunchKernelGGL((attn_group_kernel<f16_t, DK, false>), grid, block, 0, st, p);            \
+  } else if (qb) hipLaunchKernelGGL((attn_group_kernel<bf16_t, DK, true>), grid, block, 0, st, p);    \
+  else hipLaunchKernelGGL((attn_group_kernel<bf16_t, DK, false>), grid, block, 0, st, p)
   switch (a->d / a->heads) {
     case 32: NMTGAN_GROUP(32); break;
     case 64: NMTGAN_GROUP(64); break;

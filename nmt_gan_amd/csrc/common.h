@@ -64,6 +64,46 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(bf16_t, h);
 }
 
+// IEEE half as the second 16-bit operand type: 11 significand bits against bf16's 8, so an operand carries an
+// 8x smaller rounding error at the same MFMA rate; range 6e-8 .. 65504 (stores saturate instead of producing inf).
+typedef _Float16 f16_t;
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16_t f32_to_f16(float f) {
+  return (f16_t)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);        // v_cvt_f16_f32 rounds to nearest even
+}
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
+  f16x2_t h = {f32_to_f16(a), f32_to_f16(b)};
+  return __builtin_bit_cast(unsigned, h);
+}
+
+// 8 packed 16-bit elements (one 16-byte register quad) <-> 8 floats
+template <typename T> struct Pack16;
+template <> struct Pack16<bf16_t> {
+  __device__ static __forceinline__ void unpack2(unsigned w, float& lo, float& hi) {
+    lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
+  }
+  __device__ static __forceinline__ unsigned pack2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  }
+};
+template <> struct Pack16<f16_t> {
+  __device__ static __forceinline__ void unpack2(unsigned w, float& lo, float& hi) {
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, w);
+    lo = (float)h[0]; hi = (float)h[1];
+  }
+  __device__ static __forceinline__ unsigned pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+};
+template <typename T>
+__device__ __forceinline__ void unpack8(const uint4& r, float* f) {
+  Pack16<T>::unpack2(r.x, f[0], f[1]); Pack16<T>::unpack2(r.y, f[2], f[3]);
+  Pack16<T>::unpack2(r.z, f[4], f[5]); Pack16<T>::unpack2(r.w, f[6], f[7]);
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack8u(const float* f) {
+  return make_uint4(Pack16<T>::pack2(f[0], f[1]), Pack16<T>::pack2(f[2], f[3]), Pack16<T>::pack2(f[4], f[5]),
+                    Pack16<T>::pack2(f[6], f[7]));
+}
+
 template <typename T> struct OpTraits;
 template <> struct OpTraits<float> {
   static constexpr int kDtype = NMTGAN_F32;
@@ -74,6 +114,12 @@ template <> struct OpTraits<bf16_t> {
   static constexpr int kDtype = NMTGAN_BF16;
   __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
   __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+template <> struct OpTraits<f16_t> {
+  static constexpr int kDtype = NMTGAN_F16;
+  __device__ static __forceinline__ float load(const f16_t* p) { return (float)*p; }
+  __device__ static __forceinline__ void store(f16_t* p, float v) { *p = f32_to_f16(v); }
 };
 
 // Load N consecutive elements (N in {1,2,4,8,16}) as floats with the widest aligned access.
@@ -105,51 +151,61 @@ template <int N> struct VecIO<float, N> {
     }
   }
 };
-template <int N> struct VecIO<bf16_t, N> {
-  __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[N]) {
+template <typename T, int N> struct VecIO16 {
+  __device__ static __forceinline__ void load(const T* p, float (&o)[N]) {
     if constexpr (N >= 8) {
 #pragma unroll
       for (int i = 0; i < N / 8; ++i) {
-        uint4 v = reinterpret_cast<const uint4*>(p)[i];
-        unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          o[8 * i + 2 * j] = __uint_as_float(w[j] << 16);
-          o[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
-        }
+        const uint4 v = reinterpret_cast<const uint4*>(p)[i];
+        unpack8<T>(v, o + 8 * i);
       }
     } else if constexpr (N == 4) {
-      uint2 v = *reinterpret_cast<const uint2*>(p);
-      o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-      o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+      const uint2 v = *reinterpret_cast<const uint2*>(p);
+      Pack16<T>::unpack2(v.x, o[0], o[1]);
+      Pack16<T>::unpack2(v.y, o[2], o[3]);
     } else if constexpr (N == 2) {
-      unsigned v = *reinterpret_cast<const unsigned*>(p);
-      o[0] = __uint_as_float(v << 16); o[1] = __uint_as_float(v & 0xffff0000u);
+      Pack16<T>::unpack2(*reinterpret_cast<const unsigned*>(p), o[0], o[1]);
     } else {
-      o[0] = bf16_to_f32(p[0]);
+      o[0] = OpTraits<T>::load(p);
     }
   }
-  __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[N]) {
+  __device__ static __forceinline__ void store(T* p, const float (&o)[N]) {
     if constexpr (N >= 8) {
 #pragma unroll
-      for (int i = 0; i < N / 8; ++i) {
-        unsigned w[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          w[j] = (unsigned)f32_to_bf16(o[8 * i + 2 * j]) | ((unsigned)f32_to_bf16(o[8 * i + 2 * j + 1]) << 16);
-        reinterpret_cast<uint4*>(p)[i] = make_uint4(w[0], w[1], w[2], w[3]);
-      }
+      for (int i = 0; i < N / 8; ++i) reinterpret_cast<uint4*>(p)[i] = pack8u<T>(o + 8 * i);
     } else if constexpr (N == 4) {
-      unsigned a = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-      unsigned b = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
-      *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
+      *reinterpret_cast<uint2*>(p) = make_uint2(Pack16<T>::pack2(o[0], o[1]), Pack16<T>::pack2(o[2], o[3]));
     } else if constexpr (N == 2) {
-      *reinterpret_cast<unsigned*>(p) = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+      *reinterpret_cast<unsigned*>(p) = Pack16<T>::pack2(o[0], o[1]);
     } else {
-      p[0] = f32_to_bf16(o[0]);
+      OpTraits<T>::store(p, o[0]);
     }
   }
 };
+template <int N> struct VecIO<bf16_t, N> : VecIO16<bf16_t, N> {};
+template <int N> struct VecIO<f16_t, N> : VecIO16<f16_t, N> {};
+
+// 32x32x16 MFMA on 16-bit operands held as raw 16-byte register quads
+using f32x16_t = __attribute__((ext_vector_type(16))) float;
+template <typename T>
+__device__ __forceinline__ f32x16_t mfma16(const uint4& a, const uint4& b, f32x16_t c) {
+  if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+  } else {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+  }
+}
+
+// Run `...` with OpT bound to the element type of op dtype `dt` (bf16 / fp16 / fp32)
+#define NMTGAN_DISPATCH_OP(dt, OpT, ...)                                            \
+  do {                                                                              \
+    if ((dt) == NMTGAN_BF16) { using OpT = ::nmtgan::bf16_t; __VA_ARGS__; }         \
+    else if ((dt) == NMTGAN_F16) { using OpT = ::nmtgan::f16_t; __VA_ARGS__; }      \
+    else { using OpT = float; __VA_ARGS__; }                                        \
+  } while (0)
+static inline bool valid_op_dtype(int dt) { return dt == NMTGAN_BF16 || dt == NMTGAN_F16 || dt == NMTGAN_F32; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -7,6 +7,26 @@
 
 namespace nmtgan {
 
+// ------------------------------------------------------------------ zero fill
+// Every buffer the library clears goes through this kernel, never through hipMemsetAsync: a caller may capture the
+// calls into a HIP graph, and memset nodes have replayed wrongly on this platform.
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* p16, int64_t n16, unsigned char* tail, int ntail) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) p16[i] = make_uint4(0, 0, 0, 0);
+  if (i < ntail) tail[i] = 0;
+}
+int launch_zero(void* p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  NMTGAN_REQUIRE(p != nullptr && ((uintptr_t)p % 16) == 0, "zero fill: null or misaligned buffer");
+  const int64_t n16 = (int64_t)(bytes / 16);
+  const int ntail = (int)(bytes % 16);
+  const int64_t n = n16 > ntail ? n16 : ntail;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint4*)p, n16,
+                     (unsigned char*)p + n16 * 16, ntail);
+  NMTGAN_CHECK_LAUNCH("zero_fill");
+  return 0;
+}
+
 // ------------------------------------------------------------------ embedding (model.py:772-802, 506, 565)
 template <typename OpT>
 __global__ __launch_bounds__(256) void embed_kernel(nmtgan_embed_args a) {
@@ -35,9 +55,8 @@ int launch_embed(const nmtgan_embed_args* a, hipStream_t st) {
   NMTGAN_REQUIRE(a->M > 0 && a->d > 0 && a->vocab > 0 && a->max_pos > 0, "embed: bad shape");
   NMTGAN_REQUIRE(a->table && a->timing && a->tok && a->out_f32, "embed: null pointer");
   dim3 grid((a->M + 3) / 4), block(256);
-  if (a->op_dtype == NMTGAN_BF16) hipLaunchKernelGGL(embed_kernel<bf16_t>, grid, block, 0, st, *a);
-  else if (a->op_dtype == NMTGAN_F32) hipLaunchKernelGGL(embed_kernel<float>, grid, block, 0, st, *a);
-  else NMTGAN_FAIL(-2, "embed: bad op_dtype %d", a->op_dtype);
+  NMTGAN_REQUIRE(valid_op_dtype(a->op_dtype), "embed: bad op_dtype %d", a->op_dtype);
+  NMTGAN_DISPATCH_OP(a->op_dtype, OpT, hipLaunchKernelGGL(embed_kernel<OpT>, grid, block, 0, st, *a));
   NMTGAN_CHECK_LAUNCH("embed");
   return 0;
 }
@@ -98,9 +117,9 @@ int launch_add_layernorm(const nmtgan_addln_args* a, hipStream_t st) {
   if (a->M == 0) return 0;
   NMTGAN_REQUIRE(a->M > 0 && a->d > 0 && a->d % 64 == 0, "add_layernorm: bad M=%d d=%d", a->M, a->d);
   NMTGAN_REQUIRE(a->x && a->gamma && a->beta && (a->out_f32 || a->out_op), "add_layernorm: null pointer");
-  if (a->op_dtype == NMTGAN_BF16) return launch_addln_t<bf16_t>(*a, st);
-  if (a->op_dtype == NMTGAN_F32) return launch_addln_t<float>(*a, st);
-  NMTGAN_FAIL(-2, "add_layernorm: bad op_dtype %d", a->op_dtype);
+  NMTGAN_REQUIRE(valid_op_dtype(a->op_dtype), "add_layernorm: bad op_dtype %d", a->op_dtype);
+  NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return launch_addln_t<OpT>(*a, st));
+  return 0;
 }
 
 // ------------------------------------------------------------------ rollout tokens
@@ -176,8 +195,7 @@ int launch_cast_rows(const float* in, void* out, int op_dtype, int64_t n, hipStr
   if (n == 0) return 0;
   NMTGAN_REQUIRE(n % 4 == 0, "cast: n must be a multiple of 4");
   dim3 grid((unsigned)((n / 4 + 255) / 256)), block(256);
-  if (op_dtype == NMTGAN_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, grid, block, 0, st, in, (bf16_t*)out, n);
-  else hipLaunchKernelGGL(cast_kernel<float>, grid, block, 0, st, in, (float*)out, n);
+  NMTGAN_DISPATCH_OP(op_dtype, OpT, hipLaunchKernelGGL(cast_kernel<OpT>, grid, block, 0, st, in, (OpT*)out, n));
   NMTGAN_CHECK_LAUNCH("cast");
   return 0;
 }

@@ -71,6 +71,10 @@ __device__ __forceinline__ void mma_chunk<bf16_t>(const uint4& a, const uint4& b
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 template <>
+__device__ __forceinline__ void mma_chunk<f16_t>(const uint4& a, const uint4& b, f32x16& c) {
+  c = mfma16<f16_t>(a, b, c);
+}
+template <>
 __device__ __forceinline__ void mma_chunk<float>(const uint4& a, const uint4& b, f32x16& c) {
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
@@ -315,6 +319,7 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
 template <typename OpT, int MT = 2>
 __device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x16 (&acc)[MT][2], int m0, int n0, int lane,
                                               float* scr, bool f32_out, int seg, int nn0, const float* ev = nullptr) {
+  using O16 = std::conditional_t<sizeof(OpT) == 2, OpT, bf16_t>;     // 16-bit output type (never taken for fp32)
   const int fr = lane & 31, fh = lane >> 5;
   const float sc = pick3(p.seg_scale, seg);
   const int64_t ldo = pick3(p.ldo, seg);
@@ -346,7 +351,7 @@ __device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x16 (&acc)
           float x[8];
           VecIO<float, 8>::load(scr + r * 32 + 8 * (lane & 3), x);
           if (mb + r < p.M)
-            VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(outp) + (int64_t)(mb + r) * ldo + nn0 + j * 32 + 8 * (lane & 3), x);
+            VecIO<O16, 8>::store(reinterpret_cast<O16*>(outp) + (int64_t)(mb + r) * ldo + nn0 + j * 32 + 8 * (lane & 3), x);
         }
       }
     }
@@ -1033,8 +1038,9 @@ int launch_gemm_stats(int op_dtype, const void* W, int V, const void* X, int row
   p.stats = stats;
   static const bool stats_p8 = [] { const char* e = getenv("NMTGAN_STATS_P8"); return !e || atoi(e) != 0; }();
   if (stats_p8 && prefer_p8(V, rows, p.kbytes / BKB))
-    return op_dtype == NMTGAN_BF16 ? launch_p8<bf16_t, EPI_STATS>(p, st) : launch_p8<float, EPI_STATS>(p, st);
-  return op_dtype == NMTGAN_BF16 ? launch_pipe<bf16_t, EPI_STATS>(p, st) : launch_pipe<float, EPI_STATS>(p, st);
+    NMTGAN_DISPATCH_OP(op_dtype, OpT, return launch_p8<OpT, EPI_STATS>(p, st));
+  NMTGAN_DISPATCH_OP(op_dtype, OpT, return launch_pipe<OpT, EPI_STATS>(p, st));
+  return 0;
 }
 bool gemm_stats_supported(int op_dtype, int V, int K) {
   const int es = dtype_size(op_dtype);
@@ -1063,7 +1069,7 @@ int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st) {
 static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
   prof::Scope prof_scope(prof::GEMM_PROJ, st);
   NMTGAN_REQUIRE(a != nullptr, "gemm: null args");
-  NMTGAN_REQUIRE(a->op_dtype == NMTGAN_BF16 || a->op_dtype == NMTGAN_F32, "gemm: bad op_dtype %d", a->op_dtype);
+  NMTGAN_REQUIRE(valid_op_dtype(a->op_dtype), "gemm: bad op_dtype %d", a->op_dtype);
   NMTGAN_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   if (a->M == 0) return 0;
   const int es = dtype_size(a->op_dtype);
@@ -1098,14 +1104,12 @@ static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
       p.seg_scale[s] = a->seg_scale[s];
       if (s < a->n_seg) NMTGAN_REQUIRE(a->out[s] != nullptr, "gemm: null output segment %d", s);
     }
-    return a->op_dtype == NMTGAN_BF16 ? dispatch<bf16_t, NMTGAN_EPI_LINEAR>(p, st)
-                                      : dispatch<float, NMTGAN_EPI_LINEAR>(p, st);
+    NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch<OpT, NMTGAN_EPI_LINEAR>(p, st));
   } else if (a->epilogue == NMTGAN_EPI_CONVMAX) {
     NMTGAN_REQUIRE(a->a_group > 0, "gemm: CONVMAX needs a_group (windows per sentence)");
     NMTGAN_REQUIRE(a->scale && a->shift && a->pooled, "gemm: CONVMAX needs scale/shift/pooled");
     p.scale = a->scale; p.shift = a->shift; p.pooled = a->pooled; p.ld_pool = a->ld_pool;
-    return a->op_dtype == NMTGAN_BF16 ? dispatch<bf16_t, NMTGAN_EPI_CONVMAX>(p, st)
-                                      : dispatch<float, NMTGAN_EPI_CONVMAX>(p, st);
+    NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch<OpT, NMTGAN_EPI_CONVMAX>(p, st));
   }
   NMTGAN_FAIL(-2, "gemm: unknown epilogue %d", a->epilogue);
 }

@@ -48,7 +48,7 @@ static int add_ln(const nmtgan_generator* g, float* xf, const float* yf, const n
 
 static int check_generator(const nmtgan_generator* g) {
   NMTGAN_REQUIRE(g != nullptr, "generator: null");
-  NMTGAN_REQUIRE(g->op_dtype == NMTGAN_BF16 || g->op_dtype == NMTGAN_F32, "generator: bad op_dtype");
+  NMTGAN_REQUIRE(valid_op_dtype(g->op_dtype), "generator: bad op_dtype");
   NMTGAN_REQUIRE(g->d > 0 && g->d % 64 == 0 && g->d <= 1024, "generator: hidden_units must be a multiple of 64, <= 1024");
   NMTGAN_REQUIRE(g->heads > 0 && 64 % g->heads == 0 && g->d % g->heads == 0, "generator: num_heads must divide 64");
   NMTGAN_REQUIRE(g->n_blocks > 0 && g->n_blocks <= NMTGAN_MAX_BLOCKS, "generator: bad num_blocks");
@@ -149,7 +149,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
     if (c.group_R > 0) {
       // shared prefix keys once per group on MFMA -> running (o, m, l); private suffix per row after
       nmtgan_attn_group_args ga{};
-      ga.q = a.q; ga.q_bf16 = 1; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
+      ga.q = a.q; ga.q_bf16 = 1; ga.kv_dtype = op; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
       ga.k = at(c.shK, l * c.sh_layer_stride, es); ga.vt = at(c.shVt, l * c.sht_layer_stride, es);
       ga.len = c.len_sh; ga.len_padded = c.sh_Lp; ga.row_blk = c.seg1_blk; ga.row_cnt = c.seg1_cnt;
       ga.o_part = c.o_part; ga.m_part = c.m_part; ga.l_part = c.l_part;
@@ -184,7 +184,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
     NMTGAN_TRY(dense1(op, a.xo, d, M, d, d, b.cq, a.q, d, 0, qscale, 0, st));
     if (c.group_R > 0) {
       nmtgan_attn_group_args ga{};
-      ga.q = a.q; ga.q_bf16 = 1; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
+      ga.q = a.q; ga.q_bf16 = 1; ga.kv_dtype = op; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
       ga.k = at(c.crossK, l * c.cross_layer_stride, es); ga.vt = at(c.crossVt, l * c.crosst_layer_stride, es);
       ga.len = c.Ls; ga.len_padded = c.cross_Lp; ga.row_blk = c.cross_blk; ga.mask = c.x_pad; ga.out = a.ao;
       ga.slot_table = c.slot_table; ga.slots = c.slots; ga.n_entries = c.n_entries;
@@ -238,7 +238,7 @@ static int prefill(const nmtgan_generator* g, const int32_t* dec_in, const uint8
 // ------------------------------------------------------------------------------------------ discriminator
 static int check_disc(const nmtgan_discriminator* d) {
   NMTGAN_REQUIRE(d != nullptr, "discriminator: null");
-  NMTGAN_REQUIRE(d->op_dtype == NMTGAN_BF16 || d->op_dtype == NMTGAN_F32, "discriminator: bad op_dtype");
+  NMTGAN_REQUIRE(valid_op_dtype(d->op_dtype), "discriminator: bad op_dtype");
   NMTGAN_REQUIRE(d->n_widths > 0 && d->n_widths <= NMTGAN_MAX_WIDTHS, "discriminator: bad n_widths");
   NMTGAN_REQUIRE(d->Fp % 64 == 0 && d->Fp >= d->F && d->F > 0, "discriminator: Fp must be F rounded up to 64");
   NMTGAN_REQUIRE((d->dim_word * dtype_size(d->op_dtype)) % 16 == 0, "discriminator: dim_word misaligned");
@@ -294,8 +294,8 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
   NMTGAN_TRY(launch_disc_embed(tw.emb, op, &tw == &d->src ? d->vocab_s : d->vocab, ids, (int64_t)rows * T, E, b.e, st));
   if (reuse) {
     NMTGAN_TRY(launch_pool_init(reuse->pm, reuse->row_b, reuse->row_g, rows, T, Fp, b.pooled, st));
-  } else if (hipMemsetAsync(b.pooled, 0, (size_t)rows * Fp * sizeof(float), st) != hipSuccess) {
-    NMTGAN_FAIL(-3, "disc: memset failed");
+  } else {
+    NMTGAN_TRY(launch_zero(b.pooled, (size_t)rows * Fp * sizeof(float), st));
   }
   auto conv_max = [&](int i, int s0, int s1, int p0, int col) -> int {      // fused conv + BN + ReLU + max, all taps
     const int w = d->widths[i], P = T - w + 1 - p0;
@@ -404,8 +404,7 @@ static int disc_window_values(const nmtgan_discriminator* d, const nmtgan_disc_t
                               float* Cw, DiscBufs& b, hipStream_t st) {
   const int T = d->max_len, E = d->dim_word, Fp = d->Fp, op = d->op_dtype;
   NMTGAN_TRY(launch_disc_embed(tw.emb, op, d->vocab, ids, (int64_t)rows * T, E, b.e, st));
-  if (hipMemsetAsync(Cw, 0, (size_t)rows * T * Fp * sizeof(float), st) != hipSuccess)
-    NMTGAN_FAIL(-3, "disc: memset failed");
+  NMTGAN_TRY(launch_zero(Cw, (size_t)rows * T * Fp * sizeof(float), st));
   int col = 0;
   for (int i = 0; i < d->n_widths; ++i) {
     const int w = d->widths[i];
@@ -498,9 +497,9 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   b.crossV = ar.take(N * enc_rows * dm * es);
   b.shK = ar.take(N * pre_rows * dm * es);
   b.shV = ar.take(N * pre_rows * dm * es);
-  // group attention path: bf16, <= 32 rollouts per (sentence, prefix) group, MFMA-friendly head dim
+  // group attention path: 16-bit operands, <= 32 rollouts per (sentence, prefix) group, MFMA-friendly head dim
   const int dk = dm / g->heads;
-  b.group_R = (g->op_dtype == NMTGAN_BF16 && p->rollnum <= 32 && (dk == 32 || dk == 64 || dk == 128) &&
+  b.group_R = (dtype_size(g->op_dtype) == 2 && p->rollnum <= 32 && (dk == 32 || dk == 64 || dk == 128) &&
                p->n_steps >= 1) ? p->rollnum : 0;
   b.Tp = (p->T + 31) / 32 * 32;
   b.Lsp = (p->Ls + 31) / 32 * 32;
@@ -847,7 +846,8 @@ int generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* 
   hipLaunchKernelGGL(fill_greedy_tables, dim3((nfill + 255) / 256), dim3(256), 0, st, b.step_off, T, B, b.bos, b.zeros,
                      b.blk);
   NMTGAN_CHECK_LAUNCH("fill_greedy_tables");
-  if (hipMemsetAsync(y, 0, (size_t)B * T * sizeof(int32_t), st) != hipSuccess) NMTGAN_FAIL(-3, "generate: memset failed");
+  NMTGAN_REQUIRE((uintptr_t)y % 16 == 0, "generate: y must be 16-byte aligned");
+  NMTGAN_TRY(launch_zero(y, (size_t)B * T * sizeof(int32_t), st));
   SplitKScope split_k(b.splitk, b.splitk_bytes);      // single stream: the B-row step GEMMs are cut into k-slices
   for (int i = 0; i < T; ++i) {
     nmtgan_embed_args e{};

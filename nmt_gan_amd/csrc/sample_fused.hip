@@ -19,7 +19,6 @@
 namespace nmtgan {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
@@ -168,18 +167,16 @@ __global__ __launch_bounds__(256) void recompute_kernel(RecomputeParams p) {
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
   if constexpr (sizeof(OpT) == 2) {
     // S^T[vocab, row]: A = table rows (lane = vocab entry n of the 32-tile), B = hidden rows; k = 8*h2 + j
-    const bf16_t* wa = reinterpret_cast<const bf16_t*>(p.w) + ((int64_t)tile * 64 + n) * d + 8 * h2;
-    const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x) + (int64_t)row * d + 8 * h2;
+    const OpT* wa = reinterpret_cast<const OpT*>(p.w) + ((int64_t)tile * 64 + n) * d + 8 * h2;
+    const OpT* xb = reinterpret_cast<const OpT*>(p.x) + (int64_t)row * d + 8 * h2;
     for (int k1 = 0; k1 < d; k1 += 64)            // d * 2 bytes is a multiple of 128
 #pragma unroll
     for (int k0 = k1; k0 < k1 + 64; k0 += 16) {
       const uint4 a0 = *reinterpret_cast<const uint4*>(wa + k0);
       const uint4 a1 = *reinterpret_cast<const uint4*>(wa + (int64_t)32 * d + k0);
       const uint4 bb = *reinterpret_cast<const uint4*>(xb + k0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bb),
-                                                       acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bb),
-                                                       acc[1], 0, 0, 0);
+      acc[0] = mfma16<OpT>(a0, bb, acc[0]);
+      acc[1] = mfma16<OpT>(a1, bb, acc[1]);
     }
   } else {
     // fp32 MFMA takes k = h2 per instruction; a 16-byte load per lane feeds 4 of them (k permuted the
@@ -267,7 +264,7 @@ int launch_logits_sample(int op_dtype, const void* x, const void* w, int M, int 
   carve_fused((char*)ws, M, V, b);
   NMTGAN_TRY(launch_gemm_stats(op_dtype, w, V, x, M, d, b.stats, st));
   prof::Scope prof_scope(prof::SAMPLER, st);
-  if (hipMemsetAsync(b.count, 0, 1024 * sizeof(int32_t), st) != hipSuccess) NMTGAN_FAIL(-3, "logits_sample: memset failed");
+  NMTGAN_TRY(launch_zero(b.count, 1024 * sizeof(int32_t), st));
   const int tpl = (nvt + 15) / 16;
   SelectParams sp{b, nvt, tpl, M, u, u_off, u_add};
   const dim3 sgrid((M + 15) / 16);
@@ -281,8 +278,7 @@ int launch_logits_sample(int op_dtype, const void* x, const void* w, int M, int 
   NMTGAN_CHECK_LAUNCH("sample_scatter");
   RecomputeParams rp{b, x, w, d, V, out};
   const dim3 rgrid((nvt + M / 32 + 1 + 3) / 4);
-  if (op_dtype == NMTGAN_BF16) hipLaunchKernelGGL(recompute_kernel<bf16_t>, rgrid, dim3(256), 0, st, rp);
-  else hipLaunchKernelGGL(recompute_kernel<float>, rgrid, dim3(256), 0, st, rp);
+  NMTGAN_DISPATCH_OP(op_dtype, OpT, hipLaunchKernelGGL(recompute_kernel<OpT>, rgrid, dim3(256), 0, st, rp));
   NMTGAN_CHECK_LAUNCH("sample_recompute");
   return 0;
 }

@@ -745,7 +745,7 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
     nmtgan_dense w{g->softmax_w, nullptr}, gw{gr->softmax_w, nullptr};
     NMTGAN_TRY(dense_bwd(op, nullptr, b.dlo, Md, V, d, b.Xd[3 * N], 1, w, gw, b.dx, b.s, st));
   }
-  NMTGAN_REQUIRE(hipMemsetAsync(b.denc, 0, (size_t)Me * d * sizeof(float), st) == hipSuccess, "pg_grads: memset failed");
+  NMTGAN_TRY(launch_zero(b.denc, (size_t)Me * d * sizeof(float), st));
   // ---------------- backward: decoder blocks
   for (int l = N - 1; l >= 0; --l) {
     const nmtgan_dec_block& w = g->dec[l];
@@ -777,8 +777,7 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
   {
     prof::Scope prof_scope(prof::OTHER, st);
     if ((const void*)gr->emb_dst != gr->softmax_w)     // shared table: add to the softmax gradient written above
-      NMTGAN_REQUIRE(hipMemsetAsync((void*)gr->emb_dst, 0, (size_t)g->vocab_dst * d * sizeof(float), st) == hipSuccess,
-                     "pg_grads: memset failed");
+      NMTGAN_TRY(launch_zero((void*)gr->emb_dst, (size_t)g->vocab_dst * d * sizeof(float), st));
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((Md + 3) / 4), dim3(256), 0, st, b.dx, dec_in, Md, d, g->vocab_dst,
                        2.0f * g->emb_mult, (float*)gr->emb_dst);
     NMTGAN_CHECK_LAUNCH("embed_bwd");
@@ -805,8 +804,7 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
   {
     prof::Scope prof_scope(prof::OTHER, st);
     if (gr->emb_src != gr->emb_dst)
-      NMTGAN_REQUIRE(hipMemsetAsync((void*)gr->emb_src, 0, (size_t)g->vocab_src * d * sizeof(float), st) == hipSuccess,
-                     "pg_grads: memset failed");
+      NMTGAN_TRY(launch_zero((void*)gr->emb_src, (size_t)g->vocab_src * d * sizeof(float), st));
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((Me + 3) / 4), dim3(256), 0, st, b.denc, x, Me, d, g->vocab_src, g->emb_mult,
                        (float*)gr->emb_src);
     NMTGAN_CHECK_LAUNCH("embed_bwd");
@@ -1125,8 +1123,8 @@ int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p,
     const nmtgan_disc_tower_params& tp = *tps[t];
     NMTGAN_REQUIRE(tp.conv_b && tp.gamma && tp.beta && tp.moving_mean && tp.moving_var, "disc_train: null tower parameter");
     NMTGAN_TRY(launch_disc_embed(tw.emb, op, t ? d->vocab_s : d->vocab, ids[t], (int64_t)M * T, E, b.e[t], st));
-    NMTGAN_REQUIRE(hipMemsetAsync(b.pooled[t], 0, (size_t)M * Fp * sizeof(float), st) == hipSuccess &&
-                   hipMemsetAsync(b.arg[t], 0, (size_t)M * Fp * sizeof(int32_t), st) == hipSuccess, "disc_train: memset failed");
+    NMTGAN_TRY(launch_zero(b.pooled[t], (size_t)M * Fp * sizeof(float), st));
+    NMTGAN_TRY(launch_zero(b.arg[t], (size_t)M * Fp * sizeof(int32_t), st));
     int col = 0;
     float* raw = b.raw[t];
     for (int i = 0; i < d->n_widths; ++i) {
@@ -1181,7 +1179,7 @@ int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p,
     NMTGAN_TRY(launch_add_inplace(b.dH, b.dtmp, (int64_t)M * Fp, st));
     NMTGAN_TRY(dense_bwd(op, b.d_t, nullptr, M, Fp, Fp, b.pooled[t], 1, wt, gt, b.dtmp, b.s, st));
     NMTGAN_TRY(launch_add_inplace(b.dH, b.dtmp, (int64_t)M * Fp, st));
-    NMTGAN_REQUIRE(hipMemsetAsync(b.de, 0, (size_t)M * T * E * sizeof(float), st) == hipSuccess, "disc_train: memset failed");
+    NMTGAN_TRY(launch_zero(b.de, (size_t)M * T * E * sizeof(float), st));
     int col = 0;
     const float* raw = b.raw[t];
     for (int i = 0; i < d->n_widths; ++i) {
@@ -1211,7 +1209,7 @@ int disc_train_grads(const nmtgan_discriminator* d, const nmtgan_disc_params* p,
     {
       prof::Scope prof_scope(prof::OTHER, st);
       const int vocab = t ? d->vocab_s : d->vocab;
-      NMTGAN_REQUIRE(hipMemsetAsync(tg.emb, 0, (size_t)vocab * E * sizeof(float), st) == hipSuccess, "disc_train: memset failed");
+      NMTGAN_TRY(launch_zero(tg.emb, (size_t)vocab * E * sizeof(float), st));
       hipLaunchKernelGGL(embed_bwd_kernel, dim3((M * T + 3) / 4), dim3(256), 0, st, b.de, ids[t], M * T, E, vocab, 1.0f, tg.emb);
       NMTGAN_CHECK_LAUNCH("disc_embed_bwd");
     }

@@ -76,10 +76,16 @@ def disc_filters(max_len):
     return widths, [100 + 10 * w for w in widths]
 
 
-def discriminator_weights(max_len, dim_word, vocab_size, vocab_size_s, seed=1, scope="discnn") -> Dict[str, np.ndarray]:
+def discriminator_weights(max_len, dim_word, vocab_size, vocab_size_s, seed=1, scope="discnn",
+                          calibrated=False, head_scale=0.05) -> Dict[str, np.ndarray]:
     """cnn_discriminator.py:80-85, 187-191; BN moving stats randomised (mean~N(0,0.1), var~U[0.5,1.5])
-    so inference BN is not a no-op; every variable clipped to [-1,1] as the
-    reference does once at its first training step (cnn_discriminator.py:583-591)."""
+    so inference BN is not a no-op; every variable clipped to [-1,1] as the reference does once at its first
+    training step (cnn_discriminator.py:583-591).
+    calibrated=True gives the statistics a TRAINED discriminator has instead: the moving mean / variance of every
+    filter are those of its own pre-activations over random sentences (mean = conv bias, variance = sum(W^2)/3 for
+    U(-1,1) embeddings), so BatchNorm outputs are O(1) as after training (the random statistics above leave them at
+    up to +-30 for the wide filters and saturate the 2-way head), and the head is shrunk by `head_scale` so that
+    P(real) spreads over (0, 1).  Accuracy tests use it; throughput does not depend on the values."""
     rng = np.random.default_rng(seed)
     widths, nfs = disc_filters(max_len)
     E, F = dim_word, sum(nfs)
@@ -102,6 +108,14 @@ def discriminator_weights(max_len, dim_word, vocab_size, vocab_size_s, seed=1, s
         W[s + nm + "/weights"] = _glorot(rng, F, F)
     for k in W:
         np.clip(W[k], -1.0, 1.0, out=W[k])
+    if calibrated:
+        for fmt in ("conv_maxpool-%d", "conv_s_maxpool-%d"):
+            for w in widths:
+                p = s + fmt % w + "/"
+                Wc = W[p + "self_model/W"].astype(np.float64)
+                W[p + "conv_batch_norm/bn/moving_mean"] = W[p + "self_model/b"].copy()
+                W[p + "conv_batch_norm/bn/moving_variance"] = ((Wc ** 2).sum(axis=(0, 1, 2)) / 3.0).astype(np.float32)
+        W[s + "model_self/W"] = (W[s + "model_self/W"] * np.float32(head_scale)).astype(np.float32)
     return W
 
 

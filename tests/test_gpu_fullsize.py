@@ -142,11 +142,12 @@ def test_fullsize_shard_invariance(c2):
     key = np.stack([plan.row_b, plan.row_r, plan.row_g], 1)
     of, os_ = np.lexsort(key_full.T[::-1]), np.lexsort(key.T[::-1])
     assert np.array_equal(key_full[of], key[os_])
-    same = (full_rolls[of] == rolls[os_]).all(axis=1).mean()
-    print("shard vs full: identical rollouts %.5f" % same)
-    assert same > 0.999
-    if same == 1.0:
-        assert np.abs(r - c2["r"][b0:b1]).max() < 1e-3
+    same = (full_rolls[of] == rolls[os_]).all(axis=1)
+    print("shard vs full: identical rollouts %d / %d" % (same.sum(), same.size))
+    assert same.all()
+    dr = np.abs(r - c2["r"][b0:b1]).max()
+    print("shard vs full: max |reward diff| %.3g" % dr)
+    assert dr < 1e-3
 
 
 def test_fullsize_reward_tail_on_host(c2):

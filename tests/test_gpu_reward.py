@@ -51,7 +51,7 @@ def _build_setup(d, heads):
                 ref_r=ref_r, ref_rolls=ref_rolls)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("fp16", 4e-3), ("bf16", 3e-2)])
 def test_teacher_forced_logits(cuda, setup, precision, tol):
     s = setup
     m, _ = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], precision, T)
@@ -63,7 +63,7 @@ def test_teacher_forced_logits(cuda, setup, precision, tol):
     assert err < tol, err
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("fp16", 3e-3), ("bf16", 2e-2)])
 def test_discriminator_forward(cuda, setup, precision, tol):
     s = setup
     _, disc = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], precision, T)
@@ -110,14 +110,13 @@ def test_get_reward_fp32_matches_oracle(cuda, d, heads):
     ref_rows = s["ref_rolls"][plan.row_r, plan.row_g - 1, plan.row_b]
     same = (det["rollouts"][:plan.n_rows] == ref_rows).all(axis=1)
     print("fp32 rollouts identical: %d / %d" % (same.sum(), same.size))
-    assert same.mean() >= 0.995
+    assert same.all(), np.flatnonzero(~same)
     err = rel_err(det["prefix_logits"], O.teacher_forced_logits(s["W64"], s["gcfg"], torch.from_numpy(s["x"]).long(),
                                                               torch.from_numpy(s["y"]).long()).numpy())
     assert err < 1e-5, err
-    if same.all():
-        e = np.abs(r - s["ref_r"]).max()
-        print("fp32 reward abs err %.3g" % e)
-        assert e < 1e-5 * max(1.0, np.abs(s["ref_r"]).max()), e
+    e = np.abs(r - s["ref_r"]).max()
+    print("fp32 reward abs err %.3g" % e)
+    assert e < 1e-5 * max(1.0, np.abs(s["ref_r"]).max()), e
     # rows past the sample's end are masked to exactly zero, row 4 (empty sample) entirely
     assert np.all(r[s["mask"] == 0] == 0)
     assert np.all(r[4] == 0)
@@ -141,15 +140,21 @@ def test_get_reward_no_bias_fp32(cuda, setup):
     assert np.abs(r - ref).max() < 1e-5
 
 
+# 16-bit tiers on the tiny near-uniform model (V = 512): (token agreement floor, P(real) abs error) as measured
+# on MI355X with margin; the benchmark-shape figures are asserted in test_gpu_precision_c2.py
+_TIER_BOUNDS = {"fp16": (0.995, 3e-3), "bf16": (0.97, 2e-2)}
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
 @pytest.mark.parametrize("d,heads", [(64, 4), (128, 4), (256, 4), (512, 8)])
-def test_get_reward_bf16_token_agreement_and_rewards(cuda, d, heads):
-    """bf16 tier: tokens checked per step under forced-identical prefixes - the oracle replays each
+def test_get_reward_16bit_token_agreement_and_rewards(cuda, d, heads, precision):
+    """16-bit tiers: tokens checked per step under forced-identical prefixes - the oracle replays each
     GPU rollout (teacher-forced) and re-samples every position with the same uniform.
     d=64/h=4 (head dim 16) runs the per-row attention kernel, d=128/h=4 (head dim 32) the MFMA
     group-attention path used by the production shapes, d=256 additionally the fused logits+sampling
     path (no rollout logits in HBM)."""
     s = _make_setup(d, heads)
-    r, det = _gpu_reward(s, "bf16")
+    r, det = _gpu_reward(s, precision)
     plan = det["plan"]
     n = plan.n_rows
     rolls = det["rollouts"][:n]
@@ -183,18 +188,18 @@ def test_get_reward_bf16_token_agreement_and_rewards(cuda, d, heads):
         assert np.array_equal(rolls[i, :g], s["y"][b, :g])          # prefix kept
         assert np.all(rolls[i, int(lens[b]):] == 0)                 # masked tail
     frac = agree / total
-    print("bf16 token agreement under forced prefixes: %d / %d = %.4f (max |dlogit| %.3g)" % (agree, total, frac, delta))
+    print("%s token agreement under forced prefixes: %d / %d = %.4f (max |dlogit| %.3g)" % (precision, agree, total, frac, delta))
     # this synthetic model is the worst case for CDF inversion: random weights give a near-uniform
-    # distribution over V tokens, where a logit error delta flips ~0.3*delta*sqrt(V) of the draws
-    # (delta is the MAX logit error; the typical one is several times smaller, hence the 0.2)
-    V = s["gcfg"].dst_vocab_size
-    assert frac >= 1.0 - max(0.03, 0.2 * delta * V ** 0.5), (frac, delta)
+    # distribution over V tokens, where a logit error delta flips ~0.3*delta*sqrt(V) of the draws.
+    # bf16 operands miss the 99.5 % target of the north star (its floor here is the measured one); fp16 meets it
+    floor, p_tol = _TIER_BOUNDS[precision]
+    assert frac >= floor, (frac, delta)
     # rewards: oracle discriminator on the GPU's own rollouts vs the GPU's P(real)
     xp_rows = s["xp"][plan.row_b]
     p_ref = O.disc_forward(s["Wd64"], s["dcfg"], rolls.T, xp_rows.T).numpy()[:, 1]
     err = np.abs(det["p_rows"][:n] - p_ref).max()
-    print("bf16 P(real) abs err on identical rollouts: %.3g" % err)
-    assert err < 2e-2
+    print("%s P(real) abs err on identical rollouts: %.3g" % (precision, err))
+    assert err < p_tol
     assert np.all(r[s["mask"] == 0] == 0)
 
 
