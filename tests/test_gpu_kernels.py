@@ -300,7 +300,7 @@ def test_sampler_indirection_and_greedy(cuda):
 
 
 @pytest.mark.parametrize("op,M,V,d", [("bf16", 300, 32000, 512), ("bf16", 70, 4096, 256), ("fp32", 129, 2048, 128),
-                                      ("bf16", 1, 32000, 512)])
+                                      ("bf16", 1, 32000, 512), ("fp16", 300, 32000, 512), ("fp16", 33, 4096, 256)])
 def test_logits_sample_fused(cuda, op, M, V, d):
     """Fused logits + sampling (no logits in HBM) against the fp64 CDF oracle applied to the exact
     logits x . w^T of the same (op-dtype-representable) operands.  A mismatch is accepted only as a
@@ -308,7 +308,7 @@ def test_logits_sample_fused(cuda, op, M, V, d):
     from oracle import nmtgan_oracle as O
     L = _lib()
     rng = np.random.default_rng(M + V)
-    dt = torch.bfloat16 if op == "bf16" else torch.float32
+    dt, opc = L.op_dtype_of(op)
     x = torch.from_numpy(rng.standard_normal((M, d)).astype(np.float32)).to(dt)
     w = torch.from_numpy((rng.standard_normal((V, d)) * rng.choice([0.02, 0.1, 0.4], size=(1, 1))).astype(np.float32)).to(dt)
     if M > 3:
@@ -320,7 +320,6 @@ def test_logits_sample_fused(cuda, op, M, V, d):
         ubig[u_off[1] + 7] = np.float32(1.0 - 2 ** -24)
     xg, wg, ug, og = x.to(cuda), w.to(cuda), torch.from_numpy(ubig).to(cuda), torch.from_numpy(u_off).to(cuda)
     out = torch.full((M,), -1, dtype=torch.int32, device=cuda)
-    opc = L.NMTGAN_BF16 if op == "bf16" else L.NMTGAN_F32
     nb = L.lib.nmtgan_logits_sample_workspace_bytes(M, V)
     ws = torch.empty(nb, dtype=torch.uint8, device=cuda)
     L.check(L.lib.nmtgan_logits_sample(opc, xg.data_ptr(), wg.data_ptr(), M, V, d, ug.data_ptr(), og.data_ptr(), 7,
