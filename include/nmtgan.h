@@ -210,6 +210,17 @@ int nmtgan_logits_sample(int op_dtype, const void* x, const void* w, int M, int 
                          const int64_t* u_off, int64_t u_add, int32_t* out, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* nmtgan_logits_sample without a workspace argument, for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same kernels, same results as nmtgan_logits_sample; the scratch (per-tile statistics, selection arrays, counters,
+ * work list) is a static device array of NMTGAN_LOGITS_SAMPLE_STATIC_BYTES that every GPU the library runs on holds
+ * until the process ends.  The call allocates nothing; it fails with a message when
+ * nmtgan_logits_sample_workspace_bytes(M, V) exceeds the array (about 8,300 rows at V = 32000).  All calls on one
+ * GPU share the array: calls that overlap in time on the same GPU (different streams or threads) race. */
+#define NMTGAN_LOGITS_SAMPLE_STATIC_BYTES (32u << 20)
+int nmtgan_logits_sample_static(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
+                                const int64_t* u_off, int64_t u_add, int32_t* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Packed models.  All matrices Wt[N][K] in op dtype; biases / LN / BN-folded vectors fp32.
  */

@@ -125,6 +125,7 @@ EXPORTS = {
     "nmtgan_sample_rows": (i32, [C.POINTER(SampleArgs), vp]),
     "nmtgan_logits_sample_workspace_bytes": (sz, [i32, i32]),
     "nmtgan_logits_sample": (i32, [i32, vp, vp, i32, i32, i32, vp, vp, i64, vp, vp, sz, vp]),
+    "nmtgan_logits_sample_static": (i32, [i32, vp, vp, i32, i32, i32, vp, vp, i64, vp, vp]),
     "nmtgan_attn_group": (i32, [C.POINTER(AttnGroupArgs), vp]),
     "nmtgan_transpose_v": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "nmtgan_disc_workspace_bytes": (sz, [C.POINTER(Discriminator), i32]),

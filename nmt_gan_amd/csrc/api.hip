@@ -114,6 +114,10 @@ int nmtgan_logits_sample(int op_dtype, const void* x, const void* w, int M, int 
   }
   return launch_logits_sample(op_dtype, x, w, M, V, d, u, u_off, u_add, out, workspace, (hipStream_t)stream);
 }
+int nmtgan_logits_sample_static(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
+                                const int64_t* u_off, int64_t u_add, int32_t* out, void* stream) {
+  return launch_logits_sample_static(op_dtype, x, w, M, V, d, u, u_off, u_add, out, (hipStream_t)stream);
+}
 int nmtgan_sample_rows(const nmtgan_sample_args* a, void* stream) {
   return launch_sample_rows(a, (hipStream_t)stream);
 }

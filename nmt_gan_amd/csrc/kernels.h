@@ -22,6 +22,8 @@ struct SplitKScope {
 int launch_logits_sample(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
                          const int64_t* u_off, int64_t u_add, int32_t* out, void* ws, hipStream_t st);
 size_t logits_sample_workspace(int M, int V);
+int launch_logits_sample_static(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
+                                const int64_t* u_off, int64_t u_add, int32_t* out, hipStream_t st);
 int launch_zero(void* p, size_t bytes, hipStream_t st);      // fill kernel (16-byte aligned buffer); no memset nodes
 int launch_embed(const nmtgan_embed_args* a, hipStream_t st);
 int launch_add_layernorm(const nmtgan_addln_args* a, hipStream_t st);

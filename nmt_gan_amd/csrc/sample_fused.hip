@@ -13,8 +13,16 @@
 //      and finishes the upper_bound inside the tile.
 // A miss caused by the ~1e-6 mismatch between the two evaluations of a logit takes the tile's last entry.
 // HBM bytes per sampled token: ~2 x 8 x V/64 (stats) + 2 KB, against 2 x 4 x V for materialised logits.
+#include <mutex>
+
 #include "common.h"
 #include "kernels.h"
+
+// Scratch of nmtgan_logits_sample_static: the workspace of the fused logits + sampling path (per-tile softmax
+// statistics, selection arrays, counters, work list) for callers that may not allocate.  Every GPU the library runs
+// on holds its own copy of this array until the process ends; the name below is only the host-side handle of the
+// symbol - kernels get the per-device address hipGetSymbolAddress returns.
+static __device__ __align__(256) unsigned char scratch[NMTGAN_LOGITS_SAMPLE_STATIC_BYTES];
 
 namespace nmtgan {
 
@@ -247,6 +255,44 @@ __global__ __launch_bounds__(256) void recompute_kernel(RecomputeParams p) {
       }
   if (!found && h2 == 1) token = 63;
   if (token >= 0 && n < nrow) p.out[row] = min(tile * 64 + token, p.V - 1);
+}
+
+// Address of `scratch` on the current device, looked up once per device (with that device current).
+static int static_scratch_ptr(void** out) {
+  static std::mutex mu;
+  static void* ptrs[64];
+  static bool have[64];
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) NMTGAN_FAIL(-3, "logits_sample_static: no current device");
+  std::lock_guard<std::mutex> lock(mu);
+  if (!have[dev]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr)
+      NMTGAN_FAIL(-3, "logits_sample_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+    ptrs[dev] = p;
+    have[dev] = true;
+  }
+  *out = ptrs[dev];
+  return 0;
+}
+
+// Same kernels and results as launch_logits_sample; the workspace is the per-device static array above, so the
+// call allocates nothing.  Calls that overlap on one GPU share the array and race.
+int launch_logits_sample_static(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
+                                const int64_t* u_off, int64_t u_add, int32_t* out, hipStream_t st) {
+  if (M == 0) return 0;
+  NMTGAN_REQUIRE(M > 0 && V > 0 && d > 0, "logits_sample_static: bad shape M=%d V=%d d=%d", M, V, d);
+  NMTGAN_REQUIRE(valid_op_dtype(op_dtype) && gemm_stats_supported(op_dtype, V, d),
+                 "logits_sample_static: unsupported shape V=%d d=%d (V %% 64, d*esize %% 128, >= 4 k-tiles)", V, d);
+  const size_t need = logits_sample_workspace(M, V);
+  NMTGAN_REQUIRE(need <= (size_t)NMTGAN_LOGITS_SAMPLE_STATIC_BYTES,
+                 "logits_sample_static: M=%d rows x V=%d needs %zu bytes of scratch, the static buffer holds %zu "
+                 "(use nmtgan_logits_sample with a caller workspace, or fewer rows per call)",
+                 M, V, need, (size_t)NMTGAN_LOGITS_SAMPLE_STATIC_BYTES);
+  void* ws = nullptr;
+  NMTGAN_TRY(static_scratch_ptr(&ws));
+  return launch_logits_sample(op_dtype, x, w, M, V, d, u, u_off, u_add, out, ws, st);
 }
 
 size_t logits_sample_workspace(int M, int V) {
