@@ -39,7 +39,7 @@ CONFIGS = {
                T=80, V=32000, E=512),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
+MFMA_PEAK_TF = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}      # dense peaks, MI355X_MICROARCH.md
 
 
 class Cfg(dict):
@@ -89,14 +89,21 @@ def algorithmic_work(cfg, plan, B, Ls, es):
     }
 
 
-TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c2_bf16_hbm_traffic.json")
-# kernel classes -> kernels of the PMC summary (template argument 2 of the GEMM kernels is the epilogue)
+PROFILE_TAG = {"fp16": "r2_c2_fp16", "bf16": "r1_c2_bf16"}     # committed PMC summaries under profiles/
+# kernel classes -> kernels of the PMC summary (template argument 2 of the GEMM kernels is the epilogue; the element
+# type prints as `unsigned short` for bf16 and `_Float16` for fp16)
 TRAFFIC_KERNELS = {
-    "gemm_conv": r"gemm_\w+_kernel<unsigned short, 1[,>]",
-    "gemm_logits": r"gemm_\w+_kernel<unsigned short, 2[,>]",
-    "attn_self_private": r"attn_rows_bf16_kernel",
+    "gemm_conv": r"gemm_\w+_kernel<(unsigned short|_Float16), 1[,>]",
+    "gemm_logits": r"gemm_\w+_kernel<(unsigned short|_Float16), 2[,>]",
+    "attn_self_private": r"attn_rows_(bf16|16)_kernel",
     "add_layernorm": r"addln_kernel",
+    "sampler_rows": r"sample_kernel",
 }
+
+
+def _profile_file(precision, kind):
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                        "%s_%s.json" % (PROFILE_TAG.get(precision, "none"), kind))
 
 
 def committed_traffic(cls, config, precision):
@@ -105,15 +112,13 @@ def committed_traffic(cls, config, precision):
     tools/summarize_profile.py).  PMC counters cannot be collected inside the timed run, so this is the
     per-launch traffic of the same command measured beforehand; None when no summary matches."""
     import re
-    if config != "c2" or precision != "bf16" or cls not in TRAFFIC_KERNELS or not os.path.exists(TRAFFIC_FILE):
+    path = _profile_file(precision, "hbm_traffic")
+    if config != "c2" or cls not in TRAFFIC_KERNELS or not os.path.exists(path):
         return None
-    ks = json.load(open(TRAFFIC_FILE))["kernels"]
+    ks = json.load(open(path))["kernels"]
     hit = [v for k, v in ks.items() if re.search(TRAFFIC_KERNELS[cls], k)]
     n = sum(v["launches"] for v in hit)
     return round(sum(v["read_GB"] + v["write_GB"] for v in hit) * 1e9 / n) if n else None
-
-
-MFMA_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c2_bf16_mfma_util.json")
 
 
 def committed_mfma_busy(cls, config, precision):
@@ -122,9 +127,10 @@ def committed_mfma_busy(cls, config, precision):
     busy cycles / (1024 SIMDs x elapsed cycles) - utilisation at the clock the kernel ran at, where `frac` prices
     the same kernel against the 2.4 GHz spec peak.  None when no summary matches."""
     import re
-    if config != "c2" or precision != "bf16" or cls not in TRAFFIC_KERNELS or not os.path.exists(MFMA_FILE):
+    path = _profile_file(precision, "mfma_util")
+    if config != "c2" or cls not in TRAFFIC_KERNELS or not os.path.exists(path):
         return None
-    ks = json.load(open(MFMA_FILE))["kernels"]
+    ks = json.load(open(path))["kernels"]
     hit = [v for k, v in ks.items() if re.search(TRAFFIC_KERNELS[cls], k)]
     cyc = sum(v["elapsed_cycles"] for v in hit)
     return round(sum(v["mfma_busy_cycles"] for v in hit) / (1024.0 * cyc), 4) if cyc else None
@@ -176,7 +182,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"],
+                    help="MFMA operand tier: fp16 (default; meets the 1e-3 logits/rewards tolerance), bf16, fp32 (exact)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip timing the same workload on the fp32 parity tier")
+    ap.add_argument("--no-call-leg", action="store_true", help="skip timing whole Model.get_reward calls (host half included)")
     ap.add_argument("--batch", type=int, default=None, help="sentences per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -287,7 +296,7 @@ def main():
         single_ms = 1e3 * (time.perf_counter() - t1) / args.steps
 
     result = {
-        "metric": "rollout-scored sentences/sec (rollnum=16, len 50)" if args.config == "c2"
+        "metric": "rollout-scored sentences/sec (rollnum=16, len 50) at 1/2/4/8 MI355X" if args.config == "c2"
         else "rollout-scored sentences/sec (rollnum=%d, len %d)" % (R, T),
         "value": Bg * args.steps / elapsed, "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -302,6 +311,33 @@ def main():
     }
     if single_ms is not None:
         result["single_stream_ms_per_step"] = round(single_ms, 2)
+    result["value_is"] = "device-side rate: inputs, plan tables and uniforms resident in HBM, launch() only enqueues"
+
+    # whole Model.get_reward calls as gan_train.py makes them (numpy in, numpy out): host-side plan, ~15 H2D uploads,
+    # fresh Philox uniforms, the device work, the final synchronise and the D2H copy of the rewards
+    if rank == 0 and world == 1 and not args.no_call_leg:
+        model.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6)
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            model.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6)
+        result["get_reward_call_ms"] = round(1e3 * (time.perf_counter() - t2) / args.steps, 2)
+
+    # the same workload on the fp32 parity tier (the reference's arithmetic type), one timed step
+    if rank == 0 and world == 1 and args.precision != "fp32" and not args.no_fp32_leg:
+        m32 = N.Model(mcfg, precision="fp32", device=str(dev))
+        m32.build_rollout_generate(T)
+        m32.init_and_restore(weights=Wg)
+        d32 = N.DisCNN(None, T, 2, V, Bl, cfg["E"], widths, nfs, vocab_size_s=V, precision="fp32", device=str(dev))
+        d32.load_weights(Wd)
+        p32 = m32.prepare_reward(x[b0:b1], xp[b0:b1], y[b0:b1], mask[b0:b1], R, d32, T, 0.6, u, b_offset=b0, B_global=Bg)
+        p32.launch()
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        p32.launch()
+        torch.cuda.synchronize(dev)
+        result["fp32_tier_ms_per_step"] = round(1e3 * (time.perf_counter() - t3), 1)
+        result["fp32_tier_sentences_per_s"] = round(Bl / (time.perf_counter() - t3), 2)
+        del p32, m32, d32
     if args.rehearse:
         result["rehearsal"] = True
 
@@ -313,7 +349,7 @@ def main():
         _lib.lib.nmtgan_profile_start()
         prof_prep.launch()
         _lib.check(_lib.lib.nmtgan_profile_stop(ms, cnt, ncls), "profile_stop")
-        work = algorithmic_work(cfg, prep.plan, Bl, x.shape[1], 2 if args.precision == "bf16" else 4)
+        work = algorithmic_work(cfg, prep.plan, Bl, x.shape[1], 4 if args.precision == "fp32" else 2)
         rows = {}
         names = list(_lib.PROFILE_CLASSES)
         i_self, i_priv = names.index("attn_self_step"), names.index("attn_self_private")
@@ -358,8 +394,8 @@ def main():
                                       "achieved = algorithmic work of the class / summed launch time (a launch = one library GEMM "
                                       "call: a conv call split into 256-column panels + remainder shows as two kernels "
                                       "in rocprof, 201 kernels per step for these 172 launches, same total); traffic = HBM "
-                                      "bytes per launch from the committed PMC summary "
-                                      "profiles/r1_c2_bf16_hbm_traffic.json (for gemm_conv: the fused conv+max "
+                                      "bytes per launch from the committed PMC summary profiles/" + PROFILE_TAG.get(args.precision, "none") +
+                                      "_hbm_traffic.json (for gemm_conv: the fused conv+max "
                                       "kernels only; the partial-window GEMMs share their kernel with the decoder's)"}
         result["roofline_all"] = rows
         result["profiled_step_ms"] = round(profiled_ms, 2)

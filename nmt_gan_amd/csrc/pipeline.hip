@@ -313,28 +313,40 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
   for (int i = 0; i < d->n_widths; ++i) {
     const int w = d->widths[i];
     const bool buckets = reuse && bk && bk->delta > 0 && w > bk->delta;
-    // sub-ranges of REUSE_ROWS rows; p0 = first window that can contain a sampled token of any row of the
-    // sub-range (p + w > smallest give_num); neighbours with the same p0 are merged into one GEMM
+    // sub-ranges of at most REUSE_ROWS rows.  Windows every row of a sub-range shares with y_sample are skipped:
+    // p0 = first window that can contain a sampled token of any of its rows (p + w > smallest give_num); their
+    // max comes from the prefix-max table, and a max does not care which of its arguments were recomputed.
+    // With the partial-window reuse the SUM of a straddling window is split at a tap block, which rounds
+    // differently from the unsplit sum, so there the split must not depend on which rows happen to share a
+    // sub-range: it follows gq = (give_num / delta) * delta of the row itself, and a sub-range is a run of rows
+    // with equal gq - every row's score is the same under any chunking, schedule or sharding.
     for (int s0 = 0; s0 < rows;) {
-      auto g_low = [&](int lo) {
+      auto g_low = [&](int lo, int hi) {
         int g_min = T;
-        for (int r = lo; r < rows && r < lo + REUSE_ROWS; ++r) g_min = reuse->row_g_host[r] < g_min ? reuse->row_g_host[r] : g_min;
+        for (int r = lo; r < hi; ++r) g_min = reuse->row_g_host[r] < g_min ? reuse->row_g_host[r] : g_min;
         return g_min;
-      };
-      auto first_window = [&](int lo) {
-        if (!reuse) return 0;
-        const int g_min = g_low(lo);
-        return g_min - w + 1 > 0 ? g_min - w + 1 : 0;
       };
       int s1 = s0 + REUSE_ROWS < rows ? s0 + REUSE_ROWS : rows;
       if (!reuse) s1 = rows;
       if (!buckets) {
-        const int p0 = first_window(s0);
-        while (s1 < rows && first_window(s1) == p0) s1 = s1 + REUSE_ROWS < rows ? s1 + REUSE_ROWS : rows;
+        auto first_window = [&](int lo, int hi) {
+          if (!reuse) return 0;
+          const int g_min = g_low(lo, hi);
+          return g_min - w + 1 > 0 ? g_min - w + 1 : 0;
+        };
+        const int p0 = first_window(s0, s1);
+        while (s1 < rows) {
+          const int nx = s1 + REUSE_ROWS < rows ? s1 + REUSE_ROWS : rows;
+          if (first_window(s1, nx) != p0) break;
+          s1 = nx;
+        }
         NMTGAN_TRY(conv_max(i, s0, s1, p0, col));
       } else {
-        const int dl = bk->delta, g_lo = g_low(s0), es = dtype_size(op), N = d->n_filters[i], Pw = T - w + 1;
-        NMTGAN_TRY(conv_max(i, s0, s1, g_lo - dl + 1 > 0 ? g_lo - dl + 1 : 0, col));     // windows within delta of g, or behind
+        const int dl = bk->delta, es = dtype_size(op), N = d->n_filters[i], Pw = T - w + 1;
+        const int g_lo = reuse->row_g_host[s0] / dl * dl;             // gq of the run
+        s1 = s0 + 1;
+        while (s1 < rows && s1 - s0 < REUSE_ROWS && reuse->row_g_host[s1] / dl * dl == g_lo) ++s1;
+        NMTGAN_TRY(conv_max(i, s0, s1, g_lo - dl + 1 > 0 ? g_lo - dl + 1 : 0, col));     // windows within delta of gq, or behind
         for (int c = 1; c * dl <= w - 1 && c < BUCKET_MAX_C; ++c) {
           int pa = g_lo - (c + 1) * dl + 1, pb = g_lo - c * dl;
           if (pa < g_lo - w + 1) pa = g_lo - w + 1;                   // windows below hold no sampled token

@@ -207,7 +207,9 @@ def build_rollout_plan(y_sample_mask, rollnum, b_offset=0, B_global=None, r_offs
     bb = np.concatenate(bs) if bs else np.zeros(0, np.int64)
     gg = np.concatenate(gs) if gs else np.zeros(0, np.int64)
     steps = lens[bb] - 1 - gg
-    order = np.lexsort((gg, bb, -steps))                 # primary: steps desc, then b, then g
+    # primary: steps desc, then g, then b - rows of one give_num are adjacent inside a class of equal remaining
+    # steps, so the discriminator's partial-window reuse can cut its sub-ranges where give_num // taps changes
+    order = np.lexsort((bb, gg, -steps))
     bb, gg, steps = bb[order], gg[order], steps[order]
     n_grp = bb.shape[0]
     row_b = np.repeat(bb, rollnum)

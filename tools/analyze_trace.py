@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Per-step view of a rocprofv3 --kernel-trace CSV of one get_reward (tools/trace_step.sh): the dispatches of the LAST
+step are cut at the last embed-of-the-encoder boundary, kernels are shortened to a class name, and the private-suffix
+attention launches / GEMMs are listed per rollout step.  usage: tools/analyze_trace.py CSV [--kernel SUBSTR]"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("nmtgan::", "")
+    m = re.match(r"([A-Za-z0-9_]+)(<.*>)?", name)
+    base = m.group(1)
+    targs = m.group(2) or ""
+    targs = targs.replace("unsigned short", "bf16").replace("_Float16", "f16")
+    return base + targs.split("(")[0]
+
+
+def main():
+    path = sys.argv[1]
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    t = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r) for r in rows]
+    # last step: starts at the second-to-last... find embed kernels; a step = [encoder embed ... reward_reduce]
+    ends = [i for i, x in enumerate(t) if x[0].startswith("reward_reduce_kernel")]
+    if len(ends) >= 2:
+        t = t[ends[-2] + 1: ends[-1] + 1]
+    tot = defaultdict(lambda: [0, 0.0])
+    for n, s, e, _ in t:
+        tot[n][0] += 1
+        tot[n][1] += (e - s) / 1e3
+    wall = (t[-1][2] - t[0][1]) / 1e3
+    busy = sum(v[1] for v in tot.values())
+    print("step wall %.1f us, kernel busy %.1f us, %d dispatches" % (wall, busy, len(t)))
+    for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:40]:
+        print("%9.1f us %6d x %8.1f  %s" % (us, c, us / c, n[:150]))
+    if len(sys.argv) > 3 and sys.argv[2] == "--kernel":
+        sub = sys.argv[3]
+        print("--- dispatches matching", sub)
+        for i, (n, s, e, r) in enumerate(t):
+            if sub in n:
+                print("%6d %9.1f us grid %s wg %s  %s" % (i, (e - s) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", "?"), n[:100]))
+
+
+if __name__ == "__main__":
+    main()
