@@ -428,7 +428,12 @@ int nmtgan_adam_update(float* w, float* m, float* v, const float* grad, int64_t 
  * x / xs: [M][T] batch-major ids of the target / source tower; labels [M][2] one-hot rows; loss (mean of the
  * per-example losses, :343) and accuracy (:326-327): 1 float each on the device.
  * nmtgan_disc_fold_bn recomputes the inference constants (conv_scale / conv_shift of nmtgan_disc_tower) from the
- * trained vectors; nmtgan_clip_values is the one-off weight clip to [-1, 1] after the first step (:583-591, 690).
+ * trained vectors; nmtgan_clip_values is the one-off weight clip to [-1, 1] after the first step (:583-591, 690);
+ * with infinite bounds it is a plain refresh of an operand copy in any op dtype.
+ * The two gradient entry points (nmtgan_pg_grads, nmtgan_disc_train_grads) and the optimizer kernels' w_op take
+ * NMTGAN_BF16 or NMTGAN_F32 models: the backward pass keeps d(logits)-sized values in the operand type, which
+ * underflow in fp16 without loss scaling.  A model that scores in NMTGAN_F16 keeps a bf16 operand copy for its update
+ * steps and refreshes the fp16 copy from the fp32 master weights afterwards (the Python facade does).
  */
 typedef struct {
   float* emb;                                  /* [V][E] */

@@ -199,41 +199,67 @@ class DisCNN(object):
         master = torch.from_numpy(host).to(dev)
         grad = torch.zeros(off, dtype=torch.float32, device=dev)
         ms = torch.ones(off, dtype=torch.float32, device=dev)
-        opc = master.to(torch.bfloat16) if self.precision == "bf16" else None
+        # operand copies: `opc` in the model's own op dtype (scoring); an fp16 model trains on a bf16 copy (the
+        # backward pass keeps gradient-sized values in the operand type, which underflow in fp16)
+        opc = master.to(self._tdtype) if self.precision != "fp32" else None
+        opc_train = master.to(torch.bfloat16) if self.precision == "fp16" else opc
         stats = {t: (torch.from_numpy(m.copy()).to(dev), torch.from_numpy(v.copy()).to(dev)) for t, (m, v) in moving.items()}
         fold = {t: (torch.zeros(F, dtype=torch.float32, device=dev), torch.zeros(F, dtype=torch.float32, device=dev))
                 for t in moving}
-        c = _lib.Discriminator.from_buffer_copy(self._c)
         pc, gc = _lib.DiscParams(), _lib.DiscParams()
         index, col_off = {}, np.concatenate([[0], np.cumsum(self.num_filters)]).astype(int)
+
+        def build(opbuf, opcode):
+            c = _lib.Discriminator.from_buffer_copy(self._c)
+            c.op_dtype = opcode
+            for key, tf_name, kind, o, a in chunks:
+                mptr = master.data_ptr() + 4 * o
+                optr = (opbuf.data_ptr() + 2 * o) if opbuf is not None else mptr
+                if key[0] in ("tgt", "src"):
+                    ct = getattr(c, key[0])
+                    if key[1] == "emb":
+                        ct.emb = optr
+                    elif key[1] == "conv_w":
+                        ct.conv_w[self.filter_sizes.index(key[2])] = optr
+                    elif key[1] in ("hw_out", "hw_tr"):
+                        setattr(ct, key[1], optr)
+                elif key[0] == "head_w":
+                    c.head_w = mptr
+                else:
+                    c.head_b = mptr
+            for t in ("tgt", "src"):
+                ct = getattr(c, t)
+                for i in range(len(self.filter_sizes)):
+                    ct.conv_scale[i] = fold[t][0].data_ptr() + 4 * int(col_off[i])
+                    ct.conv_shift[i] = fold[t][1].data_ptr() + 4 * int(col_off[i])
+            return c
+
         for key, tf_name, kind, o, a in chunks:
             mptr, gptr = master.data_ptr() + 4 * o, grad.data_ptr() + 4 * o
-            optr = (opc.data_ptr() + 2 * o) if opc is not None else mptr
             index[key] = (tf_name, kind, o, a.size)
             if key[0] in ("tgt", "src"):
-                ct, pt, gt = getattr(c, key[0]), getattr(pc, key[0]), getattr(gc, key[0])
+                pt, gt = getattr(pc, key[0]), getattr(gc, key[0])
                 if key[1] == "emb":
-                    ct.emb, pt.emb, gt.emb = optr, mptr, gptr
+                    pt.emb, gt.emb = mptr, gptr
                 elif key[1] == "conv_w":
                     i = self.filter_sizes.index(key[2])
-                    ct.conv_w[i], pt.conv_w[i], gt.conv_w[i] = optr, mptr, gptr
-                elif key[1] in ("hw_out", "hw_tr"):
-                    setattr(ct, key[1], optr), setattr(pt, key[1], mptr), setattr(gt, key[1], gptr)
+                    pt.conv_w[i], gt.conv_w[i] = mptr, gptr
                 else:
                     setattr(pt, key[1], mptr), setattr(gt, key[1], gptr)
             elif key[0] == "head_w":
-                c.head_w, pc.head_w, gc.head_w = mptr, mptr, gptr
+                pc.head_w, gc.head_w = mptr, gptr
             else:
-                c.head_b, pc.head_b, gc.head_b = mptr, mptr, gptr
+                pc.head_b, gc.head_b = mptr, gptr
         for t in ("tgt", "src"):
-            pt, ct = getattr(pc, t), getattr(c, t)
+            pt = getattr(pc, t)
             pt.moving_mean, pt.moving_var = stats[t][0].data_ptr(), stats[t][1].data_ptr()
-            for i in range(len(self.filter_sizes)):
-                ct.conv_scale[i] = fold[t][0].data_ptr() + 4 * int(col_off[i])
-                ct.conv_shift[i] = fold[t][1].data_ptr() + 4 * int(col_off[i])
-        self._keep = [master, grad, ms, stats, fold] + ([opc] if opc is not None else [])
+        c = build(opc, self._op)
+        c_train = build(opc_train, _lib.NMTGAN_BF16) if self.precision == "fp16" else c
+        self._keep = [master, grad, ms, stats, fold] + [t for t in (opc, opc_train) if t is not None]
         self._c = c
-        self._train = dict(master=master, grad=grad, ms=ms, op=opc, pc=pc, gc=gc, index=index, n=off, stats=stats, fold=fold,
+        self._train = dict(master=master, grad=grad, ms=ms, op=opc, op_train=opc_train, c_train=c_train,
+                           op_train_code=_lib.NMTGAN_BF16 if self.precision == "fp16" else self._op,
+                           pc=pc, gc=gc, index=index, n=off, stats=stats, fold=fold,
                            steps=0, loss=torch.zeros(1, dtype=torch.float32, device=dev),
                            acc=torch.zeros(1, dtype=torch.float32, device=dev))
         self._fold_bn()
@@ -273,13 +299,14 @@ class DisCNN(object):
         dev, M = self.device, x.shape[0]
         xd, xsd = torch.from_numpy(x).to(dev), torch.from_numpy(xs).to(dev)
         ld = torch.from_numpy(lab).to(dev)
-        need = lib.nmtgan_disc_train_workspace_bytes(C.byref(self._c), M)
+        ct = tr["c_train"]
+        need = lib.nmtgan_disc_train_workspace_bytes(C.byref(ct), M)
         if need == 0:
             raise _lib.NmtGanError("disc train workspace: " + lib.nmtgan_last_error().decode())
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
         st = _lib.stream_ptr()
-        check(lib.nmtgan_disc_train_grads(C.byref(self._c), C.byref(tr["pc"]), C.byref(tr["gc"]), ptr(xd), ptr(xsd), ptr(ld), M,
+        check(lib.nmtgan_disc_train_grads(C.byref(ct), C.byref(tr["pc"]), C.byref(tr["gc"]), ptr(xd), ptr(xsd), ptr(ld), M,
                                           ptr(tr["loss"]), ptr(tr["acc"]), ptr(self._ws), self._ws.numel(), st),
               "nmtgan_disc_train_grads")
         la = torch.cat([tr["loss"], tr["acc"]])
@@ -297,24 +324,28 @@ class DisCNN(object):
             if "accum" not in tr:
                 tr["accum"], tr["accum_update"] = torch.zeros_like(tr["master"]), torch.zeros_like(tr["master"])
             check(lib.nmtgan_adadelta_update(ptr(tr["master"]), ptr(tr["accum"]), ptr(tr["accum_update"]), ptr(tr["grad"]),
-                                             tr["n"], 1.0, 0.95, 1e-6, 1.0 / world, 1.0, ptr(tr["op"]), self._op, st),
+                                             tr["n"], 1.0, 0.95, 1e-6, 1.0 / world, 1.0, ptr(tr["op_train"]), tr["op_train_code"], st),
                   "nmtgan_adadelta_update")
         elif self.optimizer_name == 'adam':       # tf.train.AdamOptimizer() defaults, :153-155
             if "adam_m" not in tr:
                 tr["adam_m"], tr["adam_v"] = torch.zeros_like(tr["master"]), torch.zeros_like(tr["master"])
             check(lib.nmtgan_adam_update(ptr(tr["master"]), ptr(tr["adam_m"]), ptr(tr["adam_v"]), ptr(tr["grad"]), tr["n"],
-                                         0.001, 0.9, 0.999, 1e-8, tr["steps"] + 1, 1.0 / world, 1.0, ptr(tr["op"]), self._op, st),
+                                         0.001, 0.9, 0.999, 1e-8, tr["steps"] + 1, 1.0 / world, 1.0, ptr(tr["op_train"]),
+                                         tr["op_train_code"], st),
                   "nmtgan_adam_update")
         elif self.optimizer_name == 'sgd':        # GradientDescentOptimizer(0.0001), :159-161
             check(lib.nmtgan_sgd_update(ptr(tr["master"]), ptr(tr["grad"]), tr["n"], self.learning_rate, 1.0 / world, 1.0,
-                                        ptr(tr["op"]), self._op, st), "nmtgan_sgd_update")
+                                        ptr(tr["op_train"]), tr["op_train_code"], st), "nmtgan_sgd_update")
         else:
             check(lib.nmtgan_rmsprop_update(ptr(tr["master"]), ptr(tr["ms"]), None, ptr(tr["grad"]), tr["n"],
-                                            self.learning_rate, 0.9, 0.0, 1e-10, 1.0 / world, 1.0, ptr(tr["op"]), self._op, st),
-                  "nmtgan_rmsprop_update")
+                                            self.learning_rate, 0.9, 0.0, 1e-10, 1.0 / world, 1.0, ptr(tr["op_train"]),
+                                            tr["op_train_code"], st), "nmtgan_rmsprop_update")
         tr["steps"] += 1
         if tr["steps"] == 1:
-            check(lib.nmtgan_clip_values(ptr(tr["master"]), tr["n"], -1.0, 1.0, ptr(tr["op"]), self._op, st),
+            check(lib.nmtgan_clip_values(ptr(tr["master"]), tr["n"], -1.0, 1.0, ptr(tr["op_train"]), tr["op_train_code"], st),
+                  "nmtgan_clip_values")
+        if tr["op"] is not None and tr["op"] is not tr["op_train"]:        # fp16 scoring copy from the updated master
+            check(lib.nmtgan_clip_values(ptr(tr["master"]), tr["n"], float("-inf"), float("inf"), ptr(tr["op"]), self._op, st),
                   "nmtgan_clip_values")
         self._fold_bn()
         torch.cuda.synchronize(dev)

@@ -1030,6 +1030,7 @@ int clip_values(float* w, int64_t n, float lo, float hi, void* w_op, int op_dtyp
   NMTGAN_REQUIRE(w && n > 0 && lo <= hi, "clip_values: bad arguments");
   dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (w_op && op_dtype == NMTGAN_BF16) hipLaunchKernelGGL(clip_values_kernel<bf16_t>, grid, block, 0, st, w, n, lo, hi, (bf16_t*)w_op);
+  else if (w_op && op_dtype == NMTGAN_F16) hipLaunchKernelGGL(clip_values_kernel<f16_t>, grid, block, 0, st, w, n, lo, hi, (f16_t*)w_op);
   else hipLaunchKernelGGL(clip_values_kernel<float>, grid, block, 0, st, w, n, lo, hi, (float*)(op_dtype == NMTGAN_F32 ? w_op : nullptr));
   NMTGAN_CHECK_LAUNCH("clip_values");
   return 0;

@@ -318,12 +318,12 @@ class Model(object):
         master = torch.from_numpy(host).to(dev)
         grad = torch.zeros(off, dtype=torch.float32, device=dev)
         ms = torch.ones(off, dtype=torch.float32, device=dev)        # RMSProp `rms` slot starts at one
-        opc = master.to(torch.bfloat16) if self.precision == "bf16" else None
-        c, gc = _lib.Generator(), _lib.Generator()
+        # operand copies: `opc` in the model's own op dtype (what get_reward / generate_step read); an fp16 model
+        # runs its update step on a bf16 copy (`opc_train`): the backward pass keeps d(logits)-sized values in the
+        # operand type and those underflow in fp16
+        opc = master.to(self._tdtype) if self.precision != "fp32" else None
+        opc_train = master.to(torch.bfloat16) if self.precision == "fp16" else opc
         old = self._c
-        for f in ("op_dtype", "d", "heads", "n_blocks", "vocab_src", "vocab_dst", "emb_mult", "timing", "max_pos"):
-            setattr(c, f, getattr(old, f))
-            setattr(gc, f, getattr(old, f))
 
         def put(struct, path, addr):
             obj = struct
@@ -331,20 +331,36 @@ class Model(object):
                 obj = obj[k] if isinstance(k, int) else getattr(obj, k)
             setattr(obj, path[-1], addr)
 
+        def build(opbuf, opcode):
+            c = _lib.Generator()
+            for f in ("op_dtype", "d", "heads", "n_blocks", "vocab_src", "vocab_dst", "emb_mult", "timing", "max_pos"):
+                setattr(c, f, getattr(old, f))
+            c.op_dtype = opcode
+            for name, kind, path, o, a in chunks:
+                use_op = opbuf is not None and kind in ("mat", "smx")
+                put(c, path, (opbuf.data_ptr() + 2 * o) if use_op else (master.data_ptr() + 4 * o))
+                if kind == "shr":          # the three roles of the shared table
+                    c.emb_dst = c.emb_src
+                    c.softmax_w = (opbuf.data_ptr() + 2 * o) if opbuf is not None else c.emb_src
+            return c
+
+        c = build(opc, self._op)
+        c_train = build(opc_train, _lib.NMTGAN_BF16) if self.precision == "fp16" else c
+        gc = _lib.Generator()
+        for f in ("op_dtype", "d", "heads", "n_blocks", "vocab_src", "vocab_dst", "emb_mult", "timing", "max_pos"):
+            setattr(gc, f, getattr(old, f))
         index = {}
         for name, kind, path, o, a in chunks:
-            use_op = opc is not None and kind in ("mat", "smx")
-            put(c, path, (opc.data_ptr() + 2 * o) if use_op else (master.data_ptr() + 4 * o))
             put(gc, path, grad.data_ptr() + 4 * o)
-            if kind == "shr":              # the three roles of the shared table; ONE gradient buffer accumulates them
-                c.emb_dst = c.emb_src
-                c.softmax_w = (opc.data_ptr() + 2 * o) if opc is not None else c.emb_src
+            if kind == "shr":              # ONE gradient buffer accumulates the three roles of the shared table
                 gc.emb_dst = gc.softmax_w = gc.emb_src
             index[name] = (kind, o, a.size)
         timing = [t for t in self._keep if t.data_ptr() == old.timing]
-        self._keep = timing + [master, grad, ms] + ([opc] if opc is not None else [])
+        self._keep = timing + [master, grad, ms] + [t for t in (opc, opc_train) if t is not None]
         self._c = c
-        self._train = dict(master=master, grad=grad, ms=ms, op=opc, gc=gc, index=index, shapes=shapes, n=off,
+        self._train = dict(master=master, grad=grad, ms=ms, op=opc, op_train=opc_train, c_train=c_train,
+                           op_train_code=_lib.NMTGAN_BF16 if self.precision == "fp16" else self._op,
+                           gc=gc, index=index, shapes=shapes, n=off,
                            loss=torch.zeros(1, dtype=torch.float32, device=dev), steps=0)
         return self._train
 
@@ -391,7 +407,7 @@ class Model(object):
         B, Ls = x.shape
         T = y.shape[1]
         tr = self._enable_training()
-        g = self.c_struct
+        g = tr["c_train"]
         xd = self._dev_i32(x)
         pad = (xd == 0).to(torch.uint8).contiguous()
         yd, dec_in = self._dev_i32(y), self._dev_i32(shift_right(y))
@@ -421,12 +437,16 @@ class Model(object):
             if "accum" not in tr:
                 tr["accum"], tr["accum_update"] = torch.zeros_like(tr["master"]), torch.zeros_like(tr["master"])
             check(lib.nmtgan_adadelta_update(ptr(tr["master"]), ptr(tr["accum"]), ptr(tr["accum_update"]), ptr(tr["grad"]),
-                                             tr["n"], 0.001, 0.95, 1e-8, 1.0 / world, 0.0, ptr(tr["op"]), self._op, st),
-                  "nmtgan_adadelta_update")
+                                             tr["n"], 0.001, 0.95, 1e-8, 1.0 / world, 0.0, ptr(tr["op_train"]),
+                                             tr["op_train_code"], st), "nmtgan_adadelta_update")
         else:
             lr = float(_cfg_get(self.config, "generator.learning_rate", 1e-5))
             check(lib.nmtgan_rmsprop_update(ptr(tr["master"]), ptr(tr["ms"]), None, ptr(tr["grad"]), tr["n"], lr, 0.9, 0.0,
-                                            1e-10, 1.0 / world, 0.0, ptr(tr["op"]), self._op, st), "nmtgan_rmsprop_update")
+                                            1e-10, 1.0 / world, 0.0, ptr(tr["op_train"]), tr["op_train_code"], st),
+                  "nmtgan_rmsprop_update")
+        if tr["op"] is not None and tr["op"] is not tr["op_train"]:        # fp16 scoring copy from the updated master
+            check(lib.nmtgan_clip_values(ptr(tr["master"]), tr["n"], float("-inf"), float("inf"), ptr(tr["op"]), self._op, st),
+                  "nmtgan_clip_values")
         tr["steps"] += 1
         torch.cuda.synchronize(self.device)
         out = float(loss.item())

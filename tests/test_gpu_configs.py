@@ -1,0 +1,228 @@
+"""The BASELINE.json configurations that are not the benchmark line, each through the C ABI on the GPU:
+  configs[0]  transformer-small d256 N2 h4 + CNN discriminator, batch 8, rollnum 4, len 30, V 32000 - the fp32 tier
+              against the committed fp64-oracle golden (tests/golden/c1_v1.npz): rollouts identical, rewards 1e-5;
+  configs[3]  transformer-big d1024 h16, rollnum 20, len 80 (8 sentences = one GPU's share): the property set of
+              test_gpu_fullsize.py (determinism, prefix kept, masks, schedules agree, reward tail on the host, first
+              sampled token = CDF inversion of the GPU's own prefix logits) and an fp64-oracle discriminator spot check;
+  configs[4]  the full GAN step's scoring half at one GPU's share (128 sentences, len 50): rollout rewards plus
+              discriminator scores of the generated and of the reference batch, checked against the fp64 oracle
+              discriminator on a sample, and against each other where the two entry points score the same rows;
+  configs[2]  (8-GPU sharding of the benchmark workload) on two ranks that share the visible GPU: a sentence-sharded
+              and a roll-sharded get_reward equal the unsharded one bit for bit (gloo carries the gather; RCCL runs
+              the same code with backend nccl)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import disc_weights, make_gpu_pair, tiny_cfgs
+from oracle import nmtgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD_C1 = os.path.join(ROOT, "tests", "golden", "c1_v1.npz")
+
+
+def test_c1_fp32_tier_reproduces_oracle_golden(cuda):
+    with np.load(GOLD_C1, allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    T, R, V = int(g["T"]), int(g["R"]), int(g["V"])
+    gcfg, dcfg = tiny_cfgs(d=int(g["D"]), blocks=int(g["BLOCKS"]), heads=int(g["HEADS"]), Vs=V, Vt=V, T=T, E=int(g["E"]))
+    Wg, Wd = O.init_generator_weights(gcfg, int(g["gen_seed"])), disc_weights(dcfg, int(g["disc_seed"]))
+    m, disc = make_gpu_pair(gcfg, dcfg, Wg, Wd, "fp32", T)
+    r = m.get_reward(g["x"], g["xp"], g["y"], g["mask"], R, disc, max_len=T, bias_num=0.6, uniforms=g["u"],
+                     return_details=True)
+    plan, det = m.last_details["plan"], m.last_details
+    want = g["rollouts"][plan.row_r, plan.row_g - 1, plan.row_b]
+    same = (det["rollouts"][:plan.n_rows] == want).all(axis=1)
+    print("C1 fp32 rollouts identical to the oracle's: %d / %d" % (same.sum(), same.size))
+    assert same.all()
+    err = float(np.abs(r - g["rewards_bias06"]).max())
+    print("C1 fp32 reward abs err %.3g" % err)
+    assert err < 1e-5
+    assert np.array_equal(m.generate_step(g["x"]), g["greedy"])
+    # the fp16 tier on the same inputs: finite, masked, in range, and the same reward on average (single rollouts
+    # diverge from the oracle's after a near-tie flip, so element-wise agreement is not expected at rollnum 4)
+    m16, d16 = make_gpu_pair(gcfg, dcfg, Wg, Wd, "fp16", T)
+    r16 = m16.get_reward(g["x"], g["xp"], g["y"], g["mask"], R, d16, max_len=T, bias_num=0.6, uniforms=g["u"])
+    assert np.isfinite(r16).all() and np.all(r16[g["mask"] == 0] == 0)
+    assert r16.min() >= -0.6 - 1e-6 and r16.max() <= 0.4 + 1e-6
+    live = g["mask"] != 0
+    assert abs(float(r16[live].mean() - g["rewards_bias06"][live].mean())) < 0.02
+
+
+def _facade_pair(d, blocks, heads, V, E, T, B, precision, calibrated=True):
+    import nmt_gan_amd as N
+    from nmt_gan_amd import synthetic
+    from nmt_gan_amd.utils import AttrDict as Cfg
+    Wg = synthetic.generator_weights(d, blocks, V, V, seed=0)
+    Wd = synthetic.discriminator_weights(T, E, V, V, seed=1, calibrated=calibrated)
+    widths, nfs = synthetic.disc_filters(T)
+    mcfg = Cfg(hidden_units=d, num_blocks=blocks, num_heads=heads, src_vocab_size=V, dst_vocab_size=V,
+               scale_embedding=True, residual_dropout_rate=0.0, train=Cfg(shared_embedding=False))
+    m = N.Model(mcfg, precision=precision)
+    m.build_generate(T)
+    m.build_rollout_generate(T)
+    m.init_and_restore(weights=Wg)
+    disc = N.DisCNN(None, T, 2, V, B, E, widths, nfs, vocab_size_s=V, precision=precision)
+    disc.load_weights(Wd)
+    return N, m, disc, Wd
+
+
+def _reward_tail(plan, p_rows, p_base, mask, R, bias):
+    """model.py:317-345 restated with numpy."""
+    B, T = mask.shape
+    q = np.zeros((B, T), np.float32)
+    for r_ in range(R):
+        add = np.repeat(p_base[:, None].astype(np.float32), T, axis=1)
+        live = plan.grp_first >= 0
+        add[:, :T - 1][live] = p_rows[plan.grp_first[live] + r_]
+        q += add
+    return ((q - np.float32(bias * R)) * mask) / np.float32(R)
+
+
+def test_c4_big_model_properties(cuda):
+    D, BLOCKS, HEADS, V, E, T, R, B = 1024, 6, 16, 32000, 512, 80, 20, 8
+    from nmt_gan_amd import synthetic
+    N, m, disc, Wd = _facade_pair(D, BLOCKS, HEADS, V, E, T, B, "fp16")
+    x, y = synthetic.synthetic_batch(B, T, V, V, seed=404)
+    y[1, 33] = O.EOS_ID
+    y[6, 3] = O.EOS_ID
+    y, mask = N.deal_generated_samples(y)
+    xp = N.extend_sentence_to_maxlen(x, T)
+    u = m.make_uniforms(R, T, B, seed=8)
+    r = m.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u, return_details=True)
+    det = m.last_details
+    plan = det["plan"]
+    rolls = det["rollouts"][:plan.n_rows]
+    assert r.shape == (B, T) and np.isfinite(r).all() and np.all(r[mask == 0] == 0)
+    live = r[mask != 0]
+    assert live.min() >= -0.6 - 1e-6 and live.max() <= 0.4 + 1e-6 and live.std() > 1e-4
+    assert plan.n_rows == R * int((plan.lens - 1).clip(min=0).sum())
+    cols = np.arange(T)[None, :]
+    keep = cols < plan.row_g[:, None]
+    tail = cols >= plan.lens[plan.row_b][:, None]
+    assert np.array_equal(rolls[keep], y[plan.row_b][keep])               # given prefix untouched
+    assert np.all(rolls[tail] == 0)                                       # masked with the sample's mask
+    samp = ~keep & ~tail
+    assert rolls[samp].min() >= 0 and rolls[samp].max() < V
+    # deterministic, and the single-stream schedule gives the same bits as the two-stream one
+    r2 = m.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u, return_details=True)
+    assert np.array_equal(r2, r) and np.array_equal(m.last_details["rollouts"], det["rollouts"])
+    try:
+        m.overlap = False
+        r3 = m.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u, return_details=True)
+    finally:
+        m.overlap = True
+    assert np.array_equal(m.last_details["rollouts"], det["rollouts"])
+    assert np.array_equal(m.last_details["p_rows"], det["p_rows"]) and np.array_equal(r3, r)
+    # reward tail recomputed on the host from the GPU's own scores
+    want = _reward_tail(plan, det["p_rows"][:plan.n_rows], det["p_base"], mask, R, 0.6)
+    assert np.abs(want - r).max() < 1e-6
+    # first sampled token of 300 rollouts = CDF inversion of the GPU's own prefix-logits row
+    un = u.cpu().numpy()
+    rng = np.random.default_rng(5)
+    bad = 0
+    for i in rng.choice(plan.n_rows, 300, replace=False):
+        b, r_, g_ = int(plan.row_b[i]), int(plan.row_r[i]), int(plan.row_g[i])
+        bad += int(O.multinomial_cdf(det["prefix_logits"][b, g_], un[r_, g_ - 1, b, g_]) != rolls[i, g_])
+    assert bad <= 1, bad
+    # discriminator spot check at T = 80 (20 widths, F = 9800) against the fp64 oracle
+    idx = rng.choice(plan.n_rows, 3, replace=False)
+    dcfg = O.DisConfig(max_len=T, dim_word=E, vocab_size=V, vocab_size_s=V)
+    p = O.disc_forward(O.to_torch(Wd), dcfg, rolls[idx].T, xp[plan.row_b[idx]].T).numpy()[:, 1]
+    err = float(np.abs(p - det["p_rows"][idx]).max())
+    print("C4 P(real) abs err vs fp64 oracle: %.3g (P = %s)" % (err, np.round(p, 4)))
+    assert err < 2e-3
+
+
+def test_c5_gan_step_scoring_at_one_gpus_share(cuda):
+    D, BLOCKS, HEADS, V, E, T, R, B = 512, 6, 8, 32000, 512, 50, 16, 128
+    from nmt_gan_amd import synthetic
+    N, m, disc, Wd = _facade_pair(D, BLOCKS, HEADS, V, E, T, B, "fp16")
+    x, y_ground = synthetic.synthetic_batch(B, T, V, V, seed=505)
+    y_sample = m.generate_step(x)                                           # gan_train.py:91
+    y_sample[5, 17] = O.EOS_ID
+    y, mask = N.deal_generated_samples(y_sample)
+    xp = N.extend_sentence_to_maxlen(x, T)
+    r = m.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6, seed=3, return_details=True)
+    det = m.last_details
+    assert r.shape == (B, T) and np.isfinite(r).all() and np.all(r[mask == 0] == 0)
+    live = r[mask != 0]
+    assert live.min() >= -0.6 - 1e-6 and live.max() <= 0.4 + 1e-6 and live.std() > 1e-4
+    # discriminator scoring of the generated and of the reference batch (the feed of model.py:311-313)
+    p_gen = disc.run_ypred_for_auc(y.T, xp.T, 1.0)
+    yg, _ = N.deal_generated_samples_to_maxlen(y_ground, {"</S>": 3}, T)
+    p_ref = disc.run_ypred_for_auc(yg.T, xp.T, 1.0)
+    assert p_gen.shape == (B, 2) and p_ref.shape == (B, 2)
+    assert np.abs(p_gen.sum(1) - 1).max() < 1e-6 and np.abs(p_ref.sum(1) - 1).max() < 1e-6
+    # the same rows scored inside get_reward (P(real) of y_sample) are the same bits
+    assert np.array_equal(p_gen[:, 1], det["p_base"])
+    # fp64 oracle discriminator on a sample of both batches
+    rng = np.random.default_rng(9)
+    idx = rng.choice(B, 4, replace=False)
+    dcfg = O.DisConfig(max_len=T, dim_word=E, vocab_size=V, vocab_size_s=V)
+    Wd64 = O.to_torch(Wd)
+    o_gen = O.disc_forward(Wd64, dcfg, y[idx].T, xp[idx].T).numpy()
+    o_ref = O.disc_forward(Wd64, dcfg, yg[idx].T, xp[idx].T).numpy()
+    err = max(float(np.abs(o_gen - p_gen[idx]).max()), float(np.abs(o_ref - p_ref[idx]).max()))
+    print("C5 discriminator abs err vs fp64 oracle (generated + reference batch): %.3g" % err)
+    assert err < 1e-3
+    # rewards follow from the scores by the reference's tail
+    plan = det["plan"]
+    want = _reward_tail(plan, det["p_rows"][:plan.n_rows], det["p_base"], mask, R, 0.6)
+    assert np.abs(want - r).max() < 1e-6
+
+
+_TWO_RANK_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from helpers import disc_weights, make_gpu_pair, tiny_cfgs
+from oracle import nmtgan_oracle as O
+rank = int(sys.argv[3])
+T = 10
+gcfg, dcfg = tiny_cfgs(d=128, heads=4, T=T)
+Wg, Wd = O.init_generator_weights(gcfg, 0), disc_weights(dcfg, 1)
+results = {}
+for precision in ("fp32", "fp16"):
+    m, disc = make_gpu_pair(gcfg, dcfg, Wg, Wd, precision, T)
+    for name, B, R in (("sentence-sharded", 5, 3), ("roll-sharded", 1, 4)):
+        x, y = O.synthetic_batch(B, T, gcfg.src_vocab_size, gcfg.dst_vocab_size, seed=7 + B, eos_rows=(0,) if B == 1 else (1,))
+        yd, mask = O.deal_generated_samples(y)
+        xp = O.extend_sentence_to_maxlen(x, T)
+        u = np.random.default_rng(B).random((R, T - 1, B, T), dtype=np.float32)
+        results[(precision, name)] = (m, disc, x, xp, yd, mask, R, u,
+                                      m.get_reward(x, xp, yd, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u, shard=False))
+print("rank", rank, "unsharded done", flush=True)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=2)
+for key, (m, disc, x, xp, yd, mask, R, u, full) in results.items():
+    got = m.get_reward(x, xp, yd, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u)
+    assert got.shape == full.shape, key
+    assert np.array_equal(got, full), (key, float(np.abs(got - full).max()))
+    # default seeds: the ranks draw the same noise (a per-model call counter), so the gathered rows are consistent
+    a = m.get_reward(x, xp, yd, mask, R, disc, max_len=T, bias_num=0.6)
+    t = torch.from_numpy(a.copy())
+    dist.broadcast(t, src=0)
+    assert np.array_equal(t.numpy(), a), key
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok", flush=True)
+'''
+
+
+def test_two_ranks_sharded_get_reward_equals_unsharded(cuda, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    port = str(29600 + os.getpid() % 2000)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    procs = [subprocess.Popen([sys.executable, "-u", str(script), ROOT, port, str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=400)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert "rank %d ok" % r in o
