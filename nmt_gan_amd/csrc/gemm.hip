@@ -4,9 +4,12 @@
 // rows of 128 BYTES per k-tile (64 bf16 or 32 fp32), 16-byte chunks XOR-swizzled by (row>>1)&7 so
 // the ds_read_b128 fragment reads of a 32-row MFMA operand are conflict-free (bank = (addr/4)%64,
 // 16-lane groups: cdna_hip_programming.md section 2).
-// Wave tile 64x64 = 2x2 MFMA 32x32 tiles:
-//   bf16: v_mfma_f32_32x32x16_bf16, one per (16-byte A chunk, 16-byte B chunk) pair
-//   fp32: v_mfma_f32_32x32x2_f32, four per chunk pair (exact fp32, the 1e-5 parity tier)
+// Wave tile 64x64 = 4x4 MFMA 16x16 tiles (the 16x16 shapes hold a higher clock under load than the 32x32 ones
+// at equal cycles per flop):
+//   bf16/fp16: v_mfma_f32_16x16x32_{bf16,f16}: lane l supplies 8 consecutive k (one 16-byte LDS chunk) of operand row
+//         l & 15; the four 16-lane groups cover 32 k, so a 128-byte k-tile is two such k-halves
+//   fp32: v_mfma_f32_16x16x4_f32, four per chunk (exact fp32, the 1e-5 parity tier)
+// C layout of a 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg.
 // The k order inside a tile is whatever the chunk order gives; A and B use the same order, so the
 // sum is over the same k set (order differs from the reference's, as any GEMM's does).
 //
@@ -30,8 +33,9 @@
 
 namespace nmtgan {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
@@ -64,22 +68,38 @@ struct GemmParams {
 };
 constexpr int EPI_STATS = 2;
 
-template <typename OpT>
-__device__ __forceinline__ void mma_chunk(const uint4& a, const uint4& b, f32x16& c);
-template <>
-__device__ __forceinline__ void mma_chunk<bf16_t>(const uint4& a, const uint4& b, f32x16& c) {
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ void mma_chunk<f16_t>(const uint4& a, const uint4& b, f32x16& c) {
-  c = mfma16<f16_t>(a, b, c);
-}
-template <>
-__device__ __forceinline__ void mma_chunk<float>(const uint4& a, const uint4& b, f32x16& c) {
-  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+// acc[I0 + i][J0 + j] += A-fragment i x B-fragment j for one k-half of a k-tile (MT x NT 16x16 tiles).  Consecutive
+// MFMAs go to different accumulators, so the dependent-accumulator latency of the fp32 shape is never exposed.
+template <typename OpT, int MT, int NT, int I0, int J0, int AM, int AN>
+__device__ __forceinline__ void mma_block(const uint4 (&fa)[MT], const uint4 (&fb)[NT], f32x4 (&acc)[AM][AN]) {
+  if constexpr (sizeof(OpT) == 4) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const unsigned au = t == 0 ? fa[i].x : (t == 1 ? fa[i].y : (t == 2 ? fa[i].z : fa[i].w));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const unsigned bu = t == 0 ? fb[j].x : (t == 1 ? fb[j].y : (t == 2 ? fb[j].z : fb[j].w));
+          acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(au), __uint_as_float(bu),
+                                                                     acc[I0 + i][J0 + j], 0, 0, 0);
+        }
+      }
+  } else if constexpr (__is_same(OpT, bf16_t)) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                      __builtin_bit_cast(bf16x8, fb[j]), acc[I0 + i][J0 + j], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i]),
+                                                                     __builtin_bit_cast(f16x8, fb[j]), acc[I0 + i][J0 + j], 0, 0, 0);
+  }
 }
 
 // element i of a 3-entry kernel-argument array WITHOUT dynamic indexing: an indexed access makes hipcc fetch
@@ -105,19 +125,19 @@ __device__ __forceinline__ int64_t a_row_offset(const GemmParams& p, int r) {
                          : (int64_t)r * p.lda_b;
 }
 
-// Epilogue of one wave's 64x64 tile.  32x32 C layout: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
+// Epilogue of one wave's (16 MT) x 64 tile.  16x16 C layout: col = lane & 15, row = 4 * (lane >> 4) + reg
 // ev: optional LDS copy of the wave's 64 per-column epilogue values ([64] bias, or [64] scale + [64] shift),
 // staged by LDS-DMA so that no compiler-visible vector load sits next to the hand-counted DMA stream
-template <typename OpT, int EPI, int MT = 2>
-__device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[MT][2], int m0, int n0, int lane,
+template <typename OpT, int EPI, int MT = 4>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int m0, int n0, int lane,
                                          const float* ev = nullptr) {
-  const int fr = lane & 31, fh = lane >> 5;
+  const int fc = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + j * 32 + fr;
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + j * 16 + fc;
     if (n >= p.N) continue;
     if constexpr (EPI == NMTGAN_EPI_LINEAR) {
-      const float bias = ev ? ev[j * 32 + fr] : (p.bias ? p.bias[n] : 0.f);
+      const float bias = ev ? ev[j * 16 + fc] : (p.bias ? p.bias[n] : 0.f);
       const int seg = (p.n_seg > 1) ? n / p.seg_width : 0;
       const int nn = (p.n_seg > 1) ? n - seg * p.seg_width : n;
       const float sc = pick3(p.seg_scale, seg);
@@ -128,8 +148,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[MT][
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + i * 16 + 4 * fq + e;
           if (m < p.M) {
             float v = (acc[i][j][e] + bias) * sc;
             if (p.relu) v = fmaxf(v, 0.f);
@@ -139,14 +159,14 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[MT][
         }
       }
     } else {
-      const float sc = ev ? ev[j * 32 + fr] : p.scale[n], sh = ev ? ev[64 + j * 32 + fr] : p.shift[n];
+      const float sc = ev ? ev[j * 16 + fc] : p.scale[n], sh = ev ? ev[64 + j * 16 + fc] : p.shift[n];
       int cur_g = -1;
       float cur_v = 0.f;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + i * 16 + 4 * fq + e;
           if (m < p.M) {
             const float v = fmaxf(acc[i][j][e] * sc + sh, 0.f);
             const int g = m / p.a_group;
@@ -167,23 +187,21 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[MT][
   }
 }
 
-// one k-tile of MFMAs for a wave: A rows at a_rd, W rows at b_rd inside `base`
+// one k-tile of MFMAs for a wave's 64x64 tile: A rows at a_rd, W rows at b_rd inside `base` (a_rd / b_rd already hold
+// the lane's row, lane & 15); fq = lane >> 4 picks the lane's 16-byte chunk inside a k-half, fsw the row's swizzle
 template <typename OpT>
-__device__ __forceinline__ void compute_tile(const unsigned char* base, int a_rd, int b_rd, int fh, int fsw,
-                                             f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void compute_tile(const unsigned char* base, int a_rd, int b_rd, int fq, int fsw,
+                                             f32x4 (&acc)[4][4]) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int pc = ((2 * q + fh) ^ fsw) << 4;
-    uint4 fa[2], fb[2];
+  for (int kh = 0; kh < 2; ++kh) {
+    const int pc = ((4 * kh + fq) ^ fsw) << 4;
+    uint4 fa[4], fb[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      fa[i] = *reinterpret_cast<const uint4*>(base + a_rd + i * 32 * BKB + pc);
-      fb[i] = *reinterpret_cast<const uint4*>(base + b_rd + i * 32 * BKB + pc);
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = *reinterpret_cast<const uint4*>(base + a_rd + i * 16 * BKB + pc);
+      fb[i] = *reinterpret_cast<const uint4*>(base + b_rd + i * 16 * BKB + pc);
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) mma_chunk<OpT>(fa[i], fb[j], acc[i][j]);
+    mma_block<OpT, 4, 4, 0, 0>(fa, fb, acc);
   }
 }
 
@@ -219,18 +237,16 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64)) void gemm_glds_kernel(G
                                        (lds_ptr_t)(smem + buf * STAGE + (wave + j * NW) * 1024), 16, 0, 0);
   };
 
-  f32x16 acc[2][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int fr = lane & 31, fh = lane >> 5;
-  const int fsw = (fr >> 1) & 7;
-  const int a_rd = (wm * 64 + fr) * BKB;
-  const int b_rd = (BM + wn * 64 + fr) * BKB;
+  const int fc = lane & 15, fq = lane >> 4;
+  const int fsw = (fc >> 1) & 7;
+  const int a_rd = (wm * 64 + fc) * BKB;
+  const int b_rd = (BM + wn * 64 + fc) * BKB;
 
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   const int kt0 = (int)((int64_t)nkt * blockIdx.y / nsl), kt1 = (int)((int64_t)nkt * (blockIdx.y + 1) / nsl);
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64)) void gemm_glds_kernel(G
   for (int kt = kt0; kt < kt1; ++kt) {
     __syncthreads();                      // vmcnt(0) + barrier: tile kt landed, buffer cur^1 free
     if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
-    compute_tile<OpT>(smem + cur * STAGE, a_rd, b_rd, fh, fsw, acc);
+    compute_tile<OpT>(smem + cur * STAGE, a_rd, b_rd, fq, fsw, acc);
     cur ^= 1;
   }
   if constexpr (EPI == NMTGAN_EPI_LINEAR) {
@@ -247,14 +263,14 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64)) void gemm_glds_kernel(G
       float* part = p.split_part + (int64_t)blockIdx.y * p.M * p.N;
       const int m0 = bm0 + wm * 64, n0 = bn0 + wn * 64;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + j * 32 + fr;
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j * 16 + fc;
         if (n >= p.N) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          for (int e = 0; e < 4; ++e) {
+            const int m = m0 + i * 16 + 4 * fq + e;
             if (m < p.M) part[(int64_t)m * p.N + n] = acc[i][j][e];
           }
       }
@@ -312,47 +328,48 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 
-// LINEAR epilogue with 16-byte stores: each 16x32 accumulator chunk is transposed through a 2 KiB
-// per-wave LDS scratch so that a store instruction writes whole 128-byte (fp32) / 64-byte (bf16) row
-// segments: 16 (fp32) or 8 (bf16) store instructions per wave tile instead of 64 scalar ones.
+// LINEAR epilogue with 16-byte stores: each 16-row x 32-column piece of the wave tile (two 16x16 accumulator tiles)
+// is transposed through a 2 KiB per-wave LDS scratch so that a store instruction writes whole 128-byte (fp32) /
+// 64-byte (16-bit) row segments: 16 (fp32) or 8 (16-bit) store instructions per 64x64 instead of 64 scalar ones.
 // Needs N % 64 == 0, segment widths % 64 == 0 and 16-byte aligned output rows (checked at launch).
-template <typename OpT, int MT = 2>
-__device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x16 (&acc)[MT][2], int m0, int n0, int lane,
+template <typename OpT, int MT = 4>
+__device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x4 (&acc)[MT][4], int m0, int n0, int lane,
                                               float* scr, bool f32_out, int seg, int nn0, const float* ev = nullptr) {
   using O16 = std::conditional_t<sizeof(OpT) == 2, OpT, bf16_t>;     // 16-bit output type (never taken for fp32)
-  const int fr = lane & 31, fh = lane >> 5;
+  const int fc = lane & 15, fq = lane >> 4;
   const float sc = pick3(p.seg_scale, seg);
   const int64_t ldo = pick3(p.ldo, seg);
   char* outp = reinterpret_cast<char*>(pick3(p.out, seg));
+  float bias[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const float bias = ev ? ev[j * 32 + fr] : (p.bias ? p.bias[n0 + j * 32 + fr] : 0.f);
+  for (int j = 0; j < 4; ++j) bias[j] = ev ? ev[j * 16 + fc] : (p.bias ? p.bias[n0 + j * 16 + fc] : 0.f);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+    for (int jp = 0; jp < 2; ++jp) {
 #pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-          float v = (acc[i][j][8 * c + e8] + bias) * sc;
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = (acc[i][2 * jp + jj][e] + bias[2 * jp + jj]) * sc;
           if (p.relu) v = fmaxf(v, 0.f);
-          scr[((e8 & 3) + 8 * (e8 >> 2) + 4 * fh) * 32 + fr] = v;
+          scr[(4 * fq + e) * 32 + 16 * jj + fc] = v;
         }
-        const int mb = m0 + i * 32 + 16 * c;
-        if (f32_out) {
+      const int mb = m0 + i * 16;
+      if (f32_out) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const int r = (lane >> 3) + 8 * t;
-            const float4 x = *reinterpret_cast<const float4*>(scr + r * 32 + 4 * (lane & 7));
-            if (mb + r < p.M)
-              *reinterpret_cast<float4*>(outp + ((int64_t)(mb + r) * ldo + nn0 + j * 32 + 4 * (lane & 7)) * 4) = x;
-          }
-        } else {
-          const int r = lane >> 2;
-          float x[8];
-          VecIO<float, 8>::load(scr + r * 32 + 8 * (lane & 3), x);
+        for (int t = 0; t < 2; ++t) {
+          const int r = (lane >> 3) + 8 * t;
+          const float4 x = *reinterpret_cast<const float4*>(scr + r * 32 + 4 * (lane & 7));
           if (mb + r < p.M)
-            VecIO<O16, 8>::store(reinterpret_cast<O16*>(outp) + (int64_t)(mb + r) * ldo + nn0 + j * 32 + 8 * (lane & 3), x);
+            *reinterpret_cast<float4*>(outp + ((int64_t)(mb + r) * ldo + nn0 + jp * 32 + 4 * (lane & 7)) * 4) = x;
         }
+      } else {
+        const int r = lane >> 2;
+        float x[8];
+        VecIO<float, 8>::load(scr + r * 32 + 8 * (lane & 3), x);
+        if (mb + r < p.M)
+          VecIO<O16, 8>::store(reinterpret_cast<O16*>(outp) + (int64_t)(mb + r) * ldo + nn0 + jp * 32 + 8 * (lane & 3), x);
       }
     }
   }
@@ -360,32 +377,32 @@ __device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x16 (&acc)
 
 // STATS epilogue (fused sampling, logits never reach HBM).  The GEMM runs TRANSPOSED: C rows = vocab
 // entries (A = softmax table), C columns = decoder rows (Wt = activations), so a decoder row is a
-// lane column of the accumulator and its 64 logits of this wave tile sit in the 2x16 registers of
-// the two half-waves: tile max and sum of exp(l - max) are in-lane reductions plus one cross-half
-// exchange.  stats[vtile][row] = (max, sum) with vtile = vocab/64; launch_logits_sample turns them
+// lane column of the accumulator and its 64 logits of this wave tile sit in 4x4 registers of each of the
+// four 16-lane groups: tile max and sum of exp(l - max) are in-lane reductions plus two cross-group
+// exchanges.  stats[vtile][row] = (max, sum) with vtile = vocab/64; launch_logits_sample turns them
 // into a sampled token (sampler.hip).
-template <int MT = 2>
-__device__ __forceinline__ void epilogue_stats(const GemmParams& p, f32x16 (&acc)[MT][2], int m0, int n0, int lane) {
-  const int fr = lane & 31, fh = lane >> 5;
+template <int MT = 4>
+__device__ __forceinline__ void epilogue_stats(const GemmParams& p, f32x4 (&acc)[MT][4], int m0, int n0, int lane) {
+  const int fc = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int ip = 0; ip < MT / 2; ++ip) {
+  for (int ip = 0; ip < MT / 4; ++ip) {
     if (m0 + 64 * ip >= p.M) continue;             // vocab size is a multiple of 64: whole tile in or out
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
       float mx = -INFINITY;
 #pragma unroll
-      for (int i = 2 * ip; i < 2 * ip + 2; ++i)
+      for (int i = 4 * ip; i < 4 * ip + 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[i][j][e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, acc[i][j][e]);
+      mx = groups4_max(mx);
       float sum = 0.f;
 #pragma unroll
-      for (int i = 2 * ip; i < 2 * ip + 2; ++i)
+      for (int i = 4 * ip; i < 4 * ip + 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f((acc[i][j][e] - mx) * 1.44269504088896341f);
-      sum += __shfl_xor(sum, 32, 64);
-      const int row = n0 + j * 32 + fr;
-      if (fh == 0 && row < p.N) p.stats[(int64_t)((m0 >> 6) + ip) * p.N + row] = make_float2(mx, sum);
+        for (int e = 0; e < 4; ++e) sum += __builtin_amdgcn_exp2f((acc[i][j][e] - mx) * 1.44269504088896341f);
+      sum = groups4_sum(sum);
+      const int row = n0 + j * 16 + fc;
+      if (fq == 0 && row < p.N) p.stats[(int64_t)((m0 >> 6) + ip) * p.N + row] = make_float2(mx, sum);
     }
   }
 }
@@ -441,18 +458,16 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
     is_buf = is_buf == 2 ? 0 : is_buf + 1;
   };
 
-  f32x16 acc[2][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int fr = lane & 31, fh = lane >> 5;
-  const int fsw = (fr >> 1) & 7;
-  const int a_rd = (wm * 64 + fr) * BKB;
-  const int b_rd = (PBM + wn * 64 + fr) * BKB;
+  const int fc = lane & 15, fq = lane >> 4;
+  const int fsw = (fc >> 1) & 7;
+  const int a_rd = (wm * 64 + fc) * BKB;
+  const int b_rd = (PBM + wn * 64 + fc) * BKB;
 
   float* scr = reinterpret_cast<float*>(smem + 3 * PSTAGE + wave * 2048);
   // vmcnt counts loads AND stores in issue order.  `pend` = epilogue stores this wave issued after its
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
   auto step = [&](bool do_issue) {               // after the wait: barrier, prefetch, 16 MFMAs per wave
     __builtin_amdgcn_s_barrier();
     if (do_issue) issue();                       // fills the stage read one iteration ago (all waves are past it)
-    compute_tile<OpT>(smem + cbuf * PSTAGE, a_rd, b_rd, fh, fsw, acc);
+    compute_tile<OpT>(smem + cbuf * PSTAGE, a_rd, b_rd, fq, fsw, acc);
     cbuf = cbuf == 2 ? 0 : cbuf + 1;
   };
   set_src((int)blockIdx.x);
@@ -501,11 +516,9 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
       epilogue<OpT, EPI>(p, acc, m0, n0, lane);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #undef NMTGAN_WAIT
 }
@@ -551,15 +564,15 @@ static int launch_pipe(GemmParams p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------ 256x256 kernel
-// Persistent 256x256 tile, 8 waves as 2 (M) x 4 (N), wave tile 128x64 = 4x2 MFMA tiles: per k-tile a wave
-// reads 24 KiB of LDS for 32 MFMAs (the 64x64 wave tile of gemm_pipe_kernel reads 16 KiB for 16, i.e. the
+// Persistent 256x256 tile, 8 waves as 2 (M) x 4 (N), wave tile 128x64 = 8x4 MFMA 16x16 tiles: per k-tile a wave
+// reads 24 KiB of LDS for 64 MFMAs (the 64x64 wave tile of gemm_pipe_kernel reads 16 KiB for 32, i.e. the
 // LDS read pipe is as busy as the matrix cores), and the block fetches 64 KiB per 8.4 MFLOP (48 per 4.2).
 // The k-tile is cut into four 16 KiB staging units - A0/A1 = the first/second 64 rows of every wave's
 // 128, B0/B1 = the first/second 32 columns of every wave's 64 - held twice (k parity): 128 KiB.
 // A k-step runs four phases, one C quadrant each:
 //     P1 (A0,B0)   P2 (A0,B1)   P3 (A1,B1)   P4 (A1,B0)
 // phase = [ds_read the operands this quadrant still lacks; issue one unit of LDS-DMA; counted vmcnt]
-//         s_barrier [8 MFMAs at raised priority] s_barrier
+//         s_barrier [16 MFMAs at raised priority] s_barrier
 // and the two wave groups (waves 0-3 / 4-7 = one wave per SIMD each) run ONE barrier apart, so on every
 // SIMD one wave feeds the matrix core while the other does its LDS reads and DMA issue.
 // Staging order A0(s+2)@P3 B0(s+2)@P4 B1(s+1)@P1 A1(s+1)@P2 keeps every unit >= 2 phases clear of its last
@@ -634,21 +647,19 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmParams p) {
     src[u][1] += adv;
   };
 
-  f32x16 acc[4][2];
+  f32x4 acc[8][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int fr = lane & 31, fh = lane >> 5;
-  const int fsw = (fr >> 1) & 7;
-  int pc[4];
+  const int fc = lane & 15, fq = lane >> 4;
+  const int fsw = (fc >> 1) & 7;
+  int pc[2];                                     // the lane's chunk in the two k-halves of a k-tile
 #pragma unroll
-  for (int q = 0; q < 4; ++q) pc[q] = ((2 * q + fh) ^ fsw) << 4;
-  const int a_rd = (wr * 64 + fr) * BKB;         // + h * QUNIT + i * 32 * BKB
-  const int b_rd = 2 * QUNIT + (wc * 32 + fr) * BKB;   // + h * QUNIT
+  for (int kh = 0; kh < 2; ++kh) pc[kh] = ((4 * kh + fq) ^ fsw) << 4;
+  const int a_rd = (wr * 64 + fc) * BKB;         // + h * QUNIT + i * 16 * BKB
+  const int b_rd = 2 * QUNIT + (wc * 32 + fc) * BKB;   // + h * QUNIT + j * 16 * BKB
   float* scr = reinterpret_cast<float*>(smem + 2 * QSTAGE + wave * 2048);
   // per-column epilogue values of the wave's 64 columns, LDS-DMA'd at the start of the tile's last k-step:
   // they ride the same in-order vmcnt stream as the tile DMAs and the epilogue needs no vector load (which
@@ -669,7 +680,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmParams p) {
     }
   };
 
-  uint4 fa[2][4], fb0[4], fb1[4];
+  uint4 fa[2][4], fb0[2][2], fb1[2][2];          // [k-half][16-row block]
 #define NMTGAN_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define NMTGAN_BAR()                       \
   do {                                     \
@@ -681,23 +692,24 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmParams p) {
   } while (0)
   auto read_a = [&](const unsigned char* base, int h) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        fa[i][q] = *reinterpret_cast<const uint4*>(base + h * QUNIT + a_rd + i * 32 * BKB + pc[q]);
+      for (int i = 0; i < 4; ++i)
+        fa[kh][i] = *reinterpret_cast<const uint4*>(base + h * QUNIT + a_rd + i * 16 * BKB + pc[kh]);
   };
-  auto read_b = [&](const unsigned char* base, int h, uint4 (&fb)[4]) {
+  auto read_b = [&](const unsigned char* base, int h, uint4 (&fb)[2][2]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) fb[q] = *reinterpret_cast<const uint4*>(base + h * QUNIT + b_rd + pc[q]);
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[kh][j] = *reinterpret_cast<const uint4*>(base + h * QUNIT + b_rd + j * 16 * BKB + pc[kh]);
   };
-  auto mfma8 = [&](auto H, auto HB, const uint4 (&fb)[4]) {
+  auto mfma8 = [&](auto H, auto HB, const uint4 (&fb)[2][2]) {      // one C quadrant: 16 MFMAs of 16x16x32
     constexpr int h = decltype(H)::value, hb = decltype(HB)::value;
     NMTGAN_BAR();
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) mma_chunk<OpT>(fa[i][q], fb[q], acc[2 * h + i][hb]);
+    mma_block<OpT, 4, 2, 4 * h, 2 * hb>(fa[0], fb[0], acc);
+    mma_block<OpT, 4, 2, 4 * h, 2 * hb>(fa[1], fb[1], acc);
     __builtin_amdgcn_s_setprio(0);
     NMTGAN_BAR();
   };
@@ -778,20 +790,18 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmParams p) {
     bool wide = false;
     if constexpr (EPI == NMTGAN_EPI_LINEAR) wide = p.wide_ok && n0 < p.N;
     if constexpr (EPI == EPI_STATS) {
-      epilogue_stats<4>(p, acc, m0, n0, lane);
+      epilogue_stats<8>(p, acc, m0, n0, lane);
     } else if (wide) {
       const int seg = (p.n_seg > 1) ? n0 / p.seg_width : 0;
       const bool f32_out = pick3(p.out_f32, seg) != 0 || sizeof(OpT) == 4;
-      epilogue_wide<OpT, 4>(p, acc, m0, n0, lane, scr, f32_out, seg, n0 - seg * p.seg_width, use_ev ? ev : nullptr);
+      epilogue_wide<OpT, 8>(p, acc, m0, n0, lane, scr, f32_out, seg, n0 - seg * p.seg_width, use_ev ? ev : nullptr);
     } else {
-      epilogue<OpT, EPI, 4>(p, acc, m0, n0, lane, use_ev ? ev : nullptr);
+      epilogue<OpT, EPI, 8>(p, acc, m0, n0, lane, use_ev ? ev : nullptr);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   if (wr == 0) NMTGAN_BAR();                     // balance the barrier count of the two groups
 #undef NMTGAN_WAIT
@@ -869,18 +879,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int fr = lane & 31, fh = lane >> 5;
-  const int fsw = (fr >> 1) & 7;
-  const int a_rd = (wm * 64 + fr) * BKB;
-  const int b_rd = GTILE + (wn * 64 + fr) * BKB;
+  const int fc = lane & 15, fq = lane >> 4;
+  const int fsw = (fc >> 1) & 7;
+  const int a_rd = (wm * 64 + fc) * BKB;
+  const int b_rd = GTILE + (wn * 64 + fc) * BKB;
 
   gload(0);
   lstore(0);
@@ -888,7 +896,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) gload(kt + 1);
-    compute_tile<OpT>(smem + cur * 2 * GTILE, a_rd, b_rd, fh, fsw, acc);
+    compute_tile<OpT>(smem + cur * 2 * GTILE, a_rd, b_rd, fq, fsw, acc);
     if (kt + 1 < nkt) lstore(cur ^ 1);
     __syncthreads();
     cur ^= 1;

@@ -676,8 +676,17 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
   };
   // target tower + head of the rollout rows [lo, hi)
   auto disc_rows = [&](int lo, int hi, hipStream_t ds) -> int {
-    for (int r0 = lo; r0 < hi; r0 += b.disc_chunk) {
-      const int rows = hi - r0 < b.disc_chunk ? hi - r0 : b.disc_chunk;
+    const int dl = b.reuse ? b.bucket.delta : 0;
+    for (int r0 = lo, rows = 0; r0 < hi; r0 += rows) {
+      rows = hi - r0 < b.disc_chunk ? hi - r0 : b.disc_chunk;
+      if (dl > 0 && r0 + rows < hi) {
+        // end the chunk where give_num / delta changes (the partial-window reuse works on runs of equal quotient,
+        // and a run cut in two costs a second, small set of conv GEMMs), unless that would leave under half a chunk
+        int cut = r0 + rows;
+        const int q = p->row_g_host[cut] / dl;
+        while (cut > r0 && p->row_g_host[cut - 1] / dl == q) --cut;
+        if (cut - r0 >= b.disc_chunk / 2) rows = cut - r0;
+      }
       PrefixReuse pr{b.win_pm, p->row_b + r0, p->row_g + r0, b.reuse ? p->row_g_host + r0 : nullptr};
       NMTGAN_TRY(disc_features_chunk(d, d->tgt, b.Y + (int64_t)r0 * T, rows, b.feat_t, b.disc, ds, b.reuse ? &pr : nullptr,
                                      b.reuse && b.bucket.delta > 0 ? &b.bucket : nullptr));
