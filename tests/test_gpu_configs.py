@@ -37,12 +37,32 @@ def test_c1_fp32_tier_reproduces_oracle_golden(cuda):
                      return_details=True)
     plan, det = m.last_details["plan"], m.last_details
     want = g["rollouts"][plan.row_r, plan.row_g - 1, plan.row_b]
-    same = (det["rollouts"][:plan.n_rows] == want).all(axis=1)
+    got = det["rollouts"][:plan.n_rows]
+    same = (got == want).all(axis=1)
     print("C1 fp32 rollouts identical to the oracle's: %d / %d" % (same.sum(), same.size))
-    assert same.all()
-    err = float(np.abs(r - g["rewards_bias06"]).max())
+    # At V = 32000 about one draw in 10^4 lies within fp32 rounding of a CDF boundary; such a rollout may leave the
+    # oracle's after that token.  It is accepted only as a STATED NEAR-TIE: at the first differing position the
+    # uniform lies within 1e-5 of the normalised CDF boundary between the two tokens (fp32-tier logits of the
+    # common prefix, fp64 CDF), and at most 3 rollouts in 856 may do so.
+    bad = np.flatnonzero(~same)
+    assert bad.size <= 3, bad
+    for i in bad:
+        b, r_, g_ = int(plan.row_b[i]), int(plan.row_r[i]), int(plan.row_g[i])
+        t = int(np.flatnonzero(got[i] != want[i])[0])
+        assert t >= g_
+        lg = m.teacher_forced_logits(g["x"][b:b + 1], got[i:i + 1])[0, t].astype(np.float64)
+        cdf = np.cumsum(np.exp(lg - lg.max()))
+        cdf /= cdf[-1]
+        lo, hi = sorted((int(got[i, t]), int(want[i, t])))
+        margin = min(abs(float(g["u"][r_, g_ - 1, b, t]) - cdf[k]) for k in range(lo, hi))
+        print("  rollout (b=%d r=%d g=%d) leaves the oracle's at t=%d: |u - boundary| = %.2e" % (b, r_, g_, t, margin))
+        assert margin < 1e-5, (i, t, margin)
+    cells = np.ones_like(g["mask"], dtype=bool)                    # reward cells fed only by identical rollouts
+    cells[plan.row_b[bad], plan.row_g[bad] - 1] = False
+    err = float(np.abs(r - g["rewards_bias06"])[cells].max())
     print("C1 fp32 reward abs err %.3g" % err)
     assert err < 1e-5
+    assert np.abs(r - g["rewards_bias06"]).max() < 0.26            # a flipped rollout moves its cell by < 1/rollnum
     assert np.array_equal(m.generate_step(g["x"]), g["greedy"])
     # the fp16 tier on the same inputs: finite, masked, in range, and the same reward on average (single rollouts
     # diverge from the oracle's after a near-tie flip, so element-wise agreement is not expected at rollnum 4)
