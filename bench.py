@@ -133,7 +133,15 @@ def committed_mfma_busy(cls, config, precision):
     ks = json.load(open(path))["kernels"]
     hit = [v for k, v in ks.items() if re.search(TRAFFIC_KERNELS[cls], k)]
     cyc = sum(v["elapsed_cycles"] for v in hit)
-    return round(sum(v["mfma_busy_cycles"] for v in hit) / (1024.0 * cyc), 4) if cyc else None
+    if not cyc:
+        return None
+    busy = sum(v["mfma_busy_cycles"] for v in hit)
+    out = {"mfma_busy_frac": round(busy / (1024.0 * cyc), 4)}
+    ns = sum(v["elapsed_cycles"] / v["effective_clock_GHz"] for v in hit if v.get("effective_clock_GHz"))
+    if ns:                                 # executed flop / dense peak at the 2.4 GHz spec clock, and the clock held
+        out["executed_frac_of_peak"] = round(busy / (1024.0 * ns * 2.4), 4)
+        out["effective_clock_GHz"] = round(cyc / ns, 3)
+    return out
 
 
 def cpu_baseline(cfg, Wg, Wd, x, y, seed_u):
@@ -375,10 +383,18 @@ def main():
             if tr is not None:                     # PMC bytes actually moved (committed summary) over the live time
                 row["traffic_per_launch"] = tr
                 row["traffic_GBps"] = round(tr * row["launches"] / (ms[i] * 1e-3) / 1e9, 1)
+                if row.get("bound") == "hbm":      # HBM bytes moved / algorithmic bytes: > 1 = re-reads, < 1 = cache hits
+                    row["traffic_over_algorithmic"] = round(tr * row["launches"] / row["algorithmic_per_step"], 3)
+            if name == "sampler_rows" and tr is not None:
+                # the rollnum rollouts of a prefix share one logits row, so most of the contract's 4V + 8 bytes per
+                # token are L2 hits: price the kernel against HBM by the bytes the fabric actually moved
+                row["algorithmic_GBps"] = row["achieved"]
+                row["achieved"] = row["traffic_GBps"]
+                row["frac"] = round(row["achieved"] / row["peak"], 4)
             if row.get("bound") == "mfma":
                 mb = committed_mfma_busy(name, args.config, args.precision)
-                if mb is not None:                 # PMC matrix-core busy fraction (committed summary)
-                    row["mfma_busy_frac"] = mb
+                if mb is not None:                 # PMC matrix-core counters (committed summary)
+                    row.update(mb)
             rows[name] = row
         top = max((k for k in rows if "bound" in rows[k]), key=lambda k: rows[k]["ms"])
         r = rows[top]

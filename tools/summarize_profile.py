@@ -29,6 +29,29 @@ def find(d, suffix):
 
 
 def short(name):
+    """Kernel name without return type, namespace and argument list; the Itanium names rocprofv3 leaves mangled
+    (its demangler does not know _Float16 template arguments) are decoded far enough to read: name<type, ints>."""
+    import re
+    m = re.match(r"_ZN6nmtgan(\d+)", name)
+    if m:
+        n = int(m.group(1))
+        ident, rest = name[m.end():m.end() + n], name[m.end() + n:]
+        args = []
+        if rest.startswith("I"):
+            rest = rest[1:]
+            while rest and not rest.startswith("E"):
+                for pat, rep in (("DF16_", "_Float16"), ("t", "unsigned short"), ("f", "float")):
+                    if rest.startswith(pat):
+                        args.append(rep)
+                        rest = rest[len(pat):]
+                        break
+                else:
+                    lit = re.match(r"L[ib](\d+)E", rest)
+                    if not lit:
+                        break
+                    args.append(lit.group(1))
+                    rest = rest[lit.end():]
+        return ident + ("<" + ", ".join(args) + ">" if args else "")
     name = name.replace("void ", "").replace("nmtgan::", "")
     return name.split("(")[0]
 
@@ -39,7 +62,10 @@ def main():
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out_dir, exist_ok=True)
     rows = list(csv.DictReader(open(find(stats_dir, "kernel_stats.csv"))))
+    label = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--label=")), "")
     with open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as f:
+        if label:
+            f.write("# %s\n" % label)
         f.write("kernel,calls,total_ms,avg_us,percent\n")
         for r in rows:
             f.write("%s,%s,%.3f,%.2f,%s\n" % (short(r["Name"]).replace(",", ";"), r["Calls"],
@@ -62,19 +88,20 @@ def main():
             out[k] = {"launches": v["launches"], "read_GB": round(v["read_bytes"] / 1e9, 3),
                       "write_GB": round(v["write_bytes"] / 1e9, 3),
                       "bytes_per_launch": round((v["read_bytes"] + v["write_bytes"]) / n)}
-        json.dump({"note": "one get_reward (C2, bf16); FETCH_SIZE x2 (gfx950) and WRITE_SIZE, KiB units",
+        json.dump({"note": "one get_reward (%s); FETCH_SIZE x2 (gfx950) and WRITE_SIZE, KiB units" % (label or tag),
                    "total_GB": round(sum(v["read_GB"] + v["write_GB"] for v in out.values()), 1), "kernels": out},
                   open(os.path.join(out_dir, tag + "_hbm_traffic.json"), "w"), indent=1)
         print("wrote", tag + "_hbm_traffic.json")
 
 
 def mfma_summary(tag, d, out_dir):
-    agg = collections.defaultdict(lambda: {"launches": 0, "busy": 0.0, "gui": 0.0})
+    agg = collections.defaultdict(lambda: {"launches": 0, "busy": 0.0, "gui": 0.0, "ns": 0.0})
     for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
         k = short(r["Kernel_Name"])
         if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
             agg[k]["busy"] += float(r["Counter_Value"])
             agg[k]["launches"] += 1
+            agg[k]["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         elif r["Counter_Name"] == "GRBM_GUI_ACTIVE":
             agg[k]["gui"] += float(r["Counter_Value"])
     out = {}
@@ -84,10 +111,14 @@ def mfma_summary(tag, d, out_dir):
         cycles = v["gui"] / 8.0
         out[k] = {"launches": v["launches"], "mfma_busy_cycles": round(v["busy"]), "elapsed_cycles": round(cycles),
                   "mfma_busy_frac": round(v["busy"] / (1024.0 * cycles), 4),
-                  "bf16_32x32x16_TFLOP": round(v["busy"] / 32.0 * 32768 / 1e12, 3)}
-    json.dump({"note": "one get_reward (C2, bf16, single-stream schedule); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
+                  "mfma_TFLOP_16bit": round(v["busy"] * 1024.0 / 1e12, 3),      # 1024 flop per busy cycle, either MFMA shape
+                  # clock the kernels held (elapsed cycles / dispatch time; reads high on dispatches under ~0.3 ms) and
+                  # the busy fraction re-priced against the 2.4 GHz spec clock = executed flop / dense peak
+                  "effective_clock_GHz": round(cycles / v["ns"], 3) if v["ns"] > 0 else None,
+                  "executed_frac_of_2p4GHz_peak": round(v["busy"] / (1024.0 * v["ns"] * 2.4), 4) if v["ns"] > 0 else None}
+    json.dump({"note": "one get_reward (" + tag + ", single-stream schedule); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
                        "(1024 SIMDs x GRBM_GUI_ACTIVE / 8); 1.0 = every matrix core issuing back to back = the dense "
-                       "bf16 peak AT THE CLOCK THE KERNEL RAN AT (DVFS holds these GEMMs near 1.5 GHz, not 2.4)",
+                       "16-bit peak AT THE CLOCK THE KERNEL RAN AT (DVFS holds these GEMMs well under 2.4 GHz)",
                "kernels": out}, open(os.path.join(out_dir, tag + "_mfma_util.json"), "w"), indent=1)
     print("wrote", tag + "_mfma_util.json")
 
