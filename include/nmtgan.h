@@ -338,9 +338,9 @@ typedef struct {
   const int32_t* grp_table; int grp_slots; const int32_t* grp_live;
   void* aux_stream;
   int aux_gemm_wgs;                 /* workgroup cap of the persistent GEMMs on aux_stream while decode steps are
-                                       still being issued (leaves CUs to the decoder); 0 = default (160) */
+                                       still being issued (leaves CUs to the decoder); 0 = default (224) */
   int aux_min_rows;                 /* finished rollouts are handed to aux_stream in batches of at least this
-                                       many rows; 0 = default (4096) */
+                                       many rows; 0 = default (6144) */
   int conv_bucket_taps;             /* partial-window reuse in the discriminator (needs row_g_host): a conv window that
                                        straddles a rollout's give point takes the sum over its leading prefix taps, in
                                        blocks of this many taps, from one pass over y_sample and only multiplies the

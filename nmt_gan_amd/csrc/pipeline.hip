@@ -645,8 +645,8 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
   SyncEvents ev;
   static const int env_wgs = [] { const char* e = getenv("NMTGAN_AUX_WGS"); return e ? atoi(e) : 0; }();
   static const int env_min = [] { const char* e = getenv("NMTGAN_AUX_MIN_ROWS"); return e ? atoi(e) : 0; }();
-  const int aux_wgs = env_wgs > 0 ? env_wgs : (p->aux_gemm_wgs > 0 ? p->aux_gemm_wgs : 160);
-  const int aux_min = env_min > 0 ? env_min : (p->aux_min_rows > 0 ? p->aux_min_rows : 4096);
+  const int aux_wgs = env_wgs > 0 ? env_wgs : (p->aux_gemm_wgs > 0 ? p->aux_gemm_wgs : 224);
+  const int aux_min = env_min > 0 ? env_min : (p->aux_min_rows > 0 ? p->aux_min_rows : 6144);
   struct CapGuard { ~CapGuard() { set_gemm_wg_cap(0); } } cap_guard;
 
   // discriminator work that does not depend on the rollouts: source tower once per sentence, target tower of

@@ -1,4 +1,6 @@
-"""Micro-benchmark of nmtgan_gemm on the shapes of the C2 workload (HIP events, random data)."""
+"""Micro-benchmark of nmtgan_gemm on the shapes of the C2 workload (HIP events, random data), with torch.matmul
+(hipBLASLt / rocBLAS) on the same box as a YARDSTICK for the dense shapes - a measuring stick only, the library
+never calls it.  usage: python tools/bench_gemm.py [bf16|fp16]"""
 import ctypes as C
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,7 +8,11 @@ import torch
 from nmt_gan_amd import _lib as L
 
 dev = torch.device("cuda:0")
+OP = sys.argv[1] if len(sys.argv) > 1 else "fp16"
+TDT, OPC = L.op_dtype_of(OP)
 SHAPES = [  # name, M, N, K, conv(P,T,E) or None, out_f32
+    ("square 4096^3", 4096, 4096, 4096, None, 0),
+    ("square 8192^3", 8192, 8192, 8192, None, 0),
     ("qkv    M49152 N1536 K512", 49152, 1536, 512, None, 0),
     ("proj   M49152 N512  K512", 49152, 512, 512, None, 1),
     ("ffn1   M49152 N2048 K512", 49152, 2048, 512, None, 0),
@@ -41,16 +47,16 @@ SHAPES = [  # name, M, N, K, conv(P,T,E) or None, out_f32
 def run(name, M, N, K, conv, out_f32, iters=10):
     g = torch.Generator(device=dev).manual_seed(1)
     a = L.GemmArgs()
-    a.op_dtype = L.NMTGAN_BF16
+    a.op_dtype = OPC
     if conv:
         P, T, E = conv
         S = M // P
-        A = (torch.rand(S * T, E, device=dev, generator=g) * 2 - 1).bfloat16()
+        A = (torch.rand(S * T, E, device=dev, generator=g) * 2 - 1).to(TDT)
         a.lda, a.a_group, a.a_group_stride = E, P, T * E
     else:
-        A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).bfloat16()
+        A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(TDT)
         a.lda = K
-    W = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).bfloat16()
+    W = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(TDT)
     a.A, a.Wt, a.M, a.N, a.K = A.data_ptr(), W.data_ptr(), M, N, K
     keep = []
     if conv and out_f32 == 2:          # window rows, LINEAR epilogue, raw fp32 out
@@ -69,7 +75,7 @@ def run(name, M, N, K, conv, out_f32, iters=10):
     else:
         a.epilogue = L.EPI_LINEAR
         bias = torch.zeros(N, device=dev)
-        out = torch.empty(M, N, device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.float32 if out_f32 else TDT)
         a.bias, a.n_seg, a.seg_width = bias.data_ptr(), 1, N
         a.out[0], a.ldo[0], a.out_f32[0], a.seg_scale[0] = out.data_ptr(), N, out_f32, 1.0
         keep += [bias, out]
@@ -83,7 +89,18 @@ def run(name, M, N, K, conv, out_f32, iters=10):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    print("%-28s %8.3f ms  %7.1f TFLOP/s" % (name, ms, 2.0 * M * N * K / ms / 1e9), flush=True)
+    ref = ""
+    if not conv:                           # same product through torch.matmul (16-bit output) as a yardstick
+        for _ in range(2):
+            torch.matmul(A, W.t())
+        e0.record()
+        for _ in range(iters):
+            torch.matmul(A, W.t())
+        e1.record()
+        torch.cuda.synchronize()
+        ms_t = e0.elapsed_time(e1) / iters
+        ref = "   torch.matmul %8.3f ms %7.1f TFLOP/s" % (ms_t, 2.0 * M * N * K / ms_t / 1e9)
+    print("%-28s %8.3f ms  %7.1f TFLOP/s%s" % (name, ms, 2.0 * M * N * K / ms / 1e9, ref), flush=True)
 
 
 if __name__ == "__main__":
