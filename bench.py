@@ -12,7 +12,7 @@ the RCCL all-gather of the reward rows.  Weak scaling: every rank (one process p
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).
+Rank 0 prints ONE JSON line (fields: this docstring and the argument help).
 """
 import argparse
 import ctypes as C
@@ -47,8 +47,7 @@ class Cfg(dict):
 
 
 def algorithmic_work(cfg, plan, B, Ls, es):
-    """Algorithmic FLOPs / bytes per kernel class for ONE get_reward (SURVEY section 8d figures;
-    derivation in DESIGN.md section 5)."""
+    """Algorithmic FLOPs / bytes per kernel class for ONE get_reward."""
     d, N, T, V, E, R = cfg["d"], cfg["blocks"], cfg["T"], cfg["V"], cfg["E"], cfg["rollnum"]
     live = plan.live.astype(np.int64)
     step_rows = int(live[1:].sum())
@@ -408,11 +407,12 @@ def main():
                                       "schedule (kernels in isolation; same schedule as `bench.py --overlap 0`, whose "
                                       "rocprofv3 --kernel-trace --stats summary is committed under profiles/); "
                                       "achieved = algorithmic work of the class / summed launch time (a launch = one library GEMM "
-                                      "call: a conv call split into 256-column panels + remainder shows as two kernels "
-                                      "in rocprof, 201 kernels per step for these 172 launches, same total); traffic = HBM "
-                                      "bytes per launch from the committed PMC summary profiles/" + PROFILE_TAG.get(args.precision, "none") +
-                                      "_hbm_traffic.json (for gemm_conv: the fused conv+max "
-                                      "kernels only; the partial-window GEMMs share their kernel with the decoder's)"}
+                                      "call; a conv call split into 256-column panels + remainder shows as two kernels in "
+                                      "rocprof, same total); traffic = HBM bytes per launch from the committed PMC summary "
+                                      "profiles/" + PROFILE_TAG.get(args.precision, "none") + "_hbm_traffic.json (for gemm_conv: "
+                                      "the fused conv+max kernels only; the partial-window GEMMs share their kernel with the "
+                                      "decoder's); mfma_busy_frac = matrix-core busy cycles / elapsed cycles at the clock the "
+                                      "kernels held (profiles/..._mfma_util.json)"}
         result["roofline_all"] = rows
         result["profiled_step_ms"] = round(profiled_ms, 2)
 

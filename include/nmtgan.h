@@ -282,7 +282,7 @@ int nmtgan_disc_head(const nmtgan_discriminator* d, const float* feat_t, const f
 /* ------------------------------------------------------------------------------------------
  * Per-prefix reward averaging.  Replaces the numpy tail of Model.get_reward (model.py:315-345):
  * Q[b,g-1] = sum_r p[grp_first[b,g-1] + r] (rolls added in r order) or rollnum adds of p_base[b]
- * when grp_first < 0 (prefix >= sentence length, SURVEY B.6); Q[b,T-1] = rollnum adds of p_base[b];
+ * when grp_first < 0 (prefix >= sentence length); Q[b,T-1] = rollnum adds of p_base[b];
  * rewards = ((Q - bias_num*rollnum) * mask) / rollnum   (bias skipped when use_bias == 0).
  */
 int nmtgan_reward_reduce(const float* p, const float* p_base, const int32_t* grp_first,
@@ -368,7 +368,7 @@ int nmtgan_teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, co
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Policy-gradient step of the generator (SURVEY section 8f-3): what gan_train.py:112 runs right after
+ * Policy-gradient step of the generator: what gan_train.py:112 runs right after
  * get_reward.  Replaces sess.run([generate_g_loss, generate_g_grad, generate_g_optm]) of
  * Model.generate_step_and_update (model.py:273-276): decoder(shift_right(Y)) (model.py:178-184) ->
  * gan_output (model.py:649-666)  loss = -sum_{b,t} softmax(logits)[b,t,Y[b,t]] * reward[b,t] / B
@@ -414,7 +414,7 @@ int nmtgan_adam_update(float* w, float* m, float* v, const float* grad, int64_t 
                        float eps, int t, float grad_scale, float grad_clip, void* w_op, int op_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Discriminator training step (SURVEY section 8f-4): one iteration of DisCNN.train (cnn_discriminator.py:664-691),
+ * Discriminator training step: one iteration of DisCNN.train (cnn_discriminator.py:664-691),
  * i.e. sess.run([train_optm, train_loss, train_accuracy, train_grads_and_vars]) for one tower: build_model
  * (cnn_discriminator.py:248-345) in TRAINING mode - BatchNorm with batch moments over (sentence, window) per filter,
  * moving statistics moved in place with decay 0.9 (conv_batch_norm, :22-33), dropout keep 1.0 (train() feeds

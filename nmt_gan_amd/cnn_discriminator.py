@@ -1,9 +1,9 @@
 """DisCNN facade: the inference surface of the reference's cnn_discriminator.DisCNN that
 Model.get_reward drives (model.py:311-313), backed by libnmtgan_hip.so.
 
-Inference (SURVEY section 8a): the two-tower multi-width CNN + highway + 2-way softmax of
+Inference: the two-tower multi-width CNN + highway + 2-way softmax of
 build_discriminator_body (cnn_discriminator.py:440-522) with BatchNorm in moving-statistics mode.
-Training (SURVEY section 8f-4): train_step() is one iteration of DisCNN.train (cnn_discriminator.py:664-691) on a
+Training: train_step() is one iteration of DisCNN.train (cnn_discriminator.py:664-691) on a
 batch the caller supplies; the file iterators around it (train(), :593-704) are data pipeline and stay out.
 """
 from __future__ import annotations
@@ -84,7 +84,7 @@ class DisCNN(object):
         return self.load_weights(tf_checkpoint.LazyCheckpoint(str(self.saveto if prefix is None else prefix)))
 
     def load_weights(self, W: Dict[str, np.ndarray]):
-        """Pack TF-named variables (SURVEY Appendix C: discnn/model_self/..., discnn/conv_maxpool-w/...)
+        """Pack TF-named variables (discnn/model_self/..., discnn/conv_maxpool-w/...)
         for the kernels: conv filters as Wt[n_w][w*E], conv bias + inference BN folded into
         scale/shift, highway matrices transposed and zero padded to Fp."""
         dev, td = self.device, self._tdtype
@@ -140,7 +140,7 @@ class DisCNN(object):
 
     # ------------------------------------------------------------------ training (row f-4)
     def _tf_names(self):
-        """(tower key, TF name prefix pieces) of both towers (SURVEY Appendix C)."""
+        """(tower key, TF name prefix pieces) of both towers."""
         s = self.scope + "/"
         return (("tgt", s + "model_self/embeddingtable", s + "conv_maxpool-%d/", s + "output_lin_0/weights",
                  s + "transform_lin_0/weights"),

@@ -4,7 +4,7 @@
 //   cross K/V         common_attention.py:383-388, once per sentence and decoder block
 //   prefill           model.py:545-618 over shift_right(y_sample): shared K/V + prefix logits
 //   rollout steps     model.py:224-245 restructured: lock-step over all live (b, r, g) rows,
-//                     one position per step, private step-major KV cache (SURVEY A.4)
+//                     one position per step, private step-major KV cache
 //   discriminator     cnn_discriminator.py:440-522, source tower once per sentence
 //   reward reduce     model.py:315-345
 #include <vector>

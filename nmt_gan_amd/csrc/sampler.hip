@@ -11,7 +11,7 @@
 //           fp64 inclusive wave scan, ballot for the first element whose CDF exceeds the target
 //           (std::upper_bound).  A miss caused by the ~1e-7 inconsistency between the two passes
 //           simply continues into the next elements; running off the end clamps to V-1 (quirk B.10).
-// Algorithmic HBM bytes per row: V*4 + 8 (SURVEY section 8d).
+// Algorithmic HBM bytes per row: V*4 + 8.
 #include "common.h"
 #include "kernels.h"
 

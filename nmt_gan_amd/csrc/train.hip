@@ -1,4 +1,4 @@
-// Policy-gradient step of the generator (SURVEY section 8f-3): the step gan_train.py:112 runs right after
+// Policy-gradient step of the generator: the step gan_train.py:112 runs right after
 // get_reward.  Reference: Model.generate_step_and_update (model.py:273-276) -> the loss half of build_generate
 // (model.py:178-190): decoder(shift_right(Y)) -> gan_output (model.py:649-666)
 //     g_loss = -sum_{b,t} softmax(logits)[b,t,Y[b,t]] * reward[b,t] / B
@@ -10,7 +10,7 @@
 //     dWt[N,K] = dY^T [N,Mp] . (X^T)^T       A = dY^T,            Wt' = X^T [K][Mp]   (Mp = M padded to 64, zeros)
 // and the row kernels below do softmax-probability loss, LayerNorm, attention, ReLU and embedding backward.
 // Gradients are fp32 in the layout of the packed weights (Wt[N][K]); residual dropout is neutralised as on the
-// rollout path (SURVEY quirk B.1).  The batch is a few thousand rows (B*T), so these kernels are sized for
+// rollout path.  The batch is a few thousand rows (B*T), so these kernels are sized for
 // correctness and determinism (fixed-order column sums; only the embedding scatter uses float atomics).
 #include <algorithm>
 #include <vector>
@@ -814,7 +814,7 @@ int pg_grads(const nmtgan_generator* g, const nmtgan_generator* gr, const int32_
 
 
 // ==========================================================================================================
-// Discriminator training step (SURVEY section 8f-4): one iteration of DisCNN.train (cnn_discriminator.py:664-691)
+// Discriminator training step: one iteration of DisCNN.train (cnn_discriminator.py:664-691)
 // = build_model (248-345) in training mode for one tower + the gradients of sum(losses).
 //   forward  embed -> per width: conv + bias (MFMA GEMM over the overlapping windows, raw fp32) -> BatchNorm with
 //            BATCH moments over (sentence, window) per filter -> ReLU -> max over time (+ argmax) -> highway ->

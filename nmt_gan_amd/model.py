@@ -9,7 +9,7 @@ get_reward_Obinforced raises NotImplementedError.
 Differences from the reference that a caller can see:
   * numpy in / numpy out is unchanged; `uniforms=` / `seed=` are keyword-only extensions that
     replace TF's unseeded Philox stream (model.py:239) with injected uniforms u[R, T-1, B, T].
-  * residual dropout, which the reference leaves ON during rollouts (SURVEY quirk B.1), is
+  * residual dropout, which the reference leaves ON during rollouts, is
     neutralised: the path is deterministic given the uniforms.
   * a call without `uniforms=` / `seed=` draws fresh noise: its seed is `reward_seed_base` plus the number of
     get_reward calls this Model has served (deterministic, and identical on every rank of a sharded job).
@@ -129,7 +129,7 @@ class Model(object):
         """Reference: model.py:425-435 (tf.train.Saver restore of the trainable variables from `modelFile`,
         or from the latest checkpoint of config.train.logdir when it is None).  `modelFile` is a TF V2
         checkpoint prefix (read by nmt_gan_amd.tf_checkpoint, no TensorFlow) or a .npz with the same
-        variable names (SURVEY Appendix C); `weights=` takes the dict directly."""
+        variable names; `weights=` takes the dict directly."""
         if weights is None:
             from . import tf_checkpoint
             if modelFile is None:
@@ -253,7 +253,7 @@ class Model(object):
     # ------------------------------------------------------------------ policy-gradient update (row f-3)
     def _param_specs(self):
         """(TF variable name, kind, path into the nmtgan_generator struct) of every trainable variable
-        (SURVEY Appendix C).  kind: mat = dense kernel packed Wt[N][K] and read in op dtype, vec = fp32 vector,
+       .  kind: mat = dense kernel packed Wt[N][K] and read in op dtype, vec = fp32 vector,
         tab = fp32 embedding table, smx = softmax table [V][d] read in op dtype."""
         if self.shared_embedding:          # one table read as source / target embedding (fp32) and softmax (op dtype)
             specs = [("embedding/shared/kernel", "shr", ("emb_src",))]
@@ -653,7 +653,7 @@ class Model(object):
         return PreparedReward(self, disc, plan, p, t, (live, step_off_h, row_g_h, grp_live), ws, details, stream)
 
     def get_reward_Obinforced(self, *a, **k):
-        raise NotImplementedError("get_reward_Obinforced is never called by the reference drivers (SURVEY section 2 #5)")
+        raise NotImplementedError("get_reward_Obinforced is never called by the reference drivers")
 
 
 class PreparedReward(object):

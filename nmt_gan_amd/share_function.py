@@ -54,7 +54,7 @@ def deal_generated_samples_to_maxlen(y_sample, dicts, maxlen):
 
 def extend_sentence_to_maxlen(seqs, maxlen=50):
     """Zero-pad every sentence to maxlen (share_function.py:240-245); like the reference it
-    raises if a sentence is longer than maxlen (SURVEY quirk B.5)."""
+    raises if a sentence is longer than maxlen."""
     x = np.zeros((len(seqs), maxlen), dtype=np.int32)
     for i, s in enumerate(seqs):
         s = np.asarray(s)
@@ -188,7 +188,7 @@ class RolloutPlan:
 
 def build_rollout_plan(y_sample_mask, rollnum, b_offset=0, B_global=None, r_offset=0) -> RolloutPlan:
     """Rows (b, r, g) for 1 <= g < len_b: for g >= len_b the masked rollout equals y_sample[b]
-    (model.py:307; SURVEY B.6), so those are scored once through p_base.  Row (b, r, g) samples
+    (model.py:307), so those are scored once through p_base.  Row (b, r, g) samples
     positions g .. len_b-1: the first from the shared prefix logits, then len_b-1-g private steps.
     Uniforms are addressed by GLOBAL sentence index (local b + b_offset) and GLOBAL roll index (local r +
     r_offset, for a shard that holds only some rolls of a sentence) so any sharding draws identical tokens."""

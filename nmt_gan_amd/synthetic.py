@@ -1,4 +1,4 @@
-"""Synthetic weights and inputs of the benchmark shapes (SURVEY section 8d, Appendix C): random
+"""Synthetic weights and inputs of the benchmark shapes: random
 initialisation with the reference's initialisers, TF variable names.  There is no network for
 datasets or checkpoints; bench.py and smoke() say `data: synthetic`."""
 from __future__ import annotations

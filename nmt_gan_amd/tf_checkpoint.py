@@ -1,10 +1,10 @@
-"""TensorFlow V2 checkpoint ("tensor bundle") reader/writer in pure Python + numpy (SURVEY section 8f-2).
+"""TensorFlow V2 checkpoint ("tensor bundle") reader/writer in pure Python + numpy.
 
 The reference keeps its weights in tf.train.Saver bundles: the generator restores its trainable
 variables from `modelFile` or the latest checkpoint of `config.train.logdir` (model.py:425-435) and
 saves after every generator iteration (gan_train.py:118); the discriminator restores every variable of
 its scope from `saveto` (cnn_discriminator.py:202-217).  This module reads such a bundle into the
-{variable name: ndarray} dict the facades' load_weights() take (names in SURVEY Appendix C), and writes
+{variable name: ndarray} dict the facades' load_weights() take (the reference's TF variable names), and writes
 one, with nothing executed from the file and no TensorFlow.
 
 Format, restated from TensorFlow 1.x (tensorflow/core/util/tensor_bundle, core/lib/io/table*; TF is

@@ -7,7 +7,7 @@ import it.  The product package (nmt_gan_amd/) never imports, calls or falls bac
 to anything in oracle/.
 
 PARITY UNPINNED: the reference (Python 2 + TensorFlow 1.2) cannot be run here, it
-ships no tests, fixtures or golden vectors (SURVEY.md §4, §8c), and every arithmetic
+ships no tests, fixtures or golden vectors, and every arithmetic
 kernel lives in TensorFlow (`tensorflow>=1.2.0`, requirements.txt:3), which is not
 under /root/reference.  The TF-kernel semantics restated here that the reference
 source does not show (recalled from upstream TF 1.x, unverifiable offline):
@@ -24,7 +24,7 @@ Each function cites the reference file:line it follows (paths relative to
     re-decode per sampled token, all-position logits, encoder re-run per rollout
     call, source tower recomputed per discriminator call (model.py:224-245,
     291-346).  Used for the CPU timing baseline.
-  * incremental: KV-cached single-position decoding (SURVEY Appendix A.4); proves
+  * incremental: KV-cached single-position decoding; proves
     the restructuring used on the GPU is result-identical.
 """
 from __future__ import annotations
@@ -92,7 +92,7 @@ def _trunc_normal(rng, shape, std):
 
 
 def init_generator_weights(cfg: GenConfig, seed: int = 0, randomize_affine: bool = True) -> Dict[str, np.ndarray]:
-    """Synthetic generator weights with the reference initialisers (SURVEY Appendix C).
+    """Synthetic generator weights with the reference initialisers.
 
     Names are the TF variable names of model.py:496,514,555,575,773-819 with the conv
     kernels squeezed from [1,1,din,dout] to [din,dout].  `randomize_affine` also
@@ -151,7 +151,7 @@ def init_disc_weights(cfg: DisConfig, seed: int = 1, randomize_bn: bool = True,
     """Synthetic discriminator weights (cnn_discriminator.py:80-85, 187-191, 43-47, 24-32).
 
     BN moving stats are randomised (mean~N(0,0.1), var~U[0.5,1.5], gamma with a few
-    negative entries) so inference BN is not a no-op (SURVEY §8d).  `clip_unit` applies
+    negative entries) so inference BN is not a no-op.  `clip_unit` applies
     the reference's one-off clip of every D variable to [-1,1]
     (cnn_discriminator.py:583-591, 690-691).
     """
@@ -229,7 +229,7 @@ def timing_signal(length: int, channels: int) -> np.ndarray:
 
 
 def multinomial_cdf(logits_row: np.ndarray, u) -> int:
-    """tf.multinomial CPU kernel semantics (SURVEY A.5; model.py:235-241), injected uniform u.
+    """tf.multinomial CPU kernel semantics (model.py:235-241), injected uniform u.
 
     c_k = sum_{j<=k} exp(l_j - max) in fp64, index order; token = min{k: c_k > u*c_{V-1}},
     clamped to V-1 (quirk B.10).
@@ -368,7 +368,7 @@ def rollout_full(W, cfg, x, y, give_num: int, u_rg: np.ndarray, max_len: int) ->
 
 
 class IncrementalDecoder:
-    """KV-cached single-position decoder (SURVEY A.4): same math as `decoder`, one position
+    """KV-cached single-position decoder: same math as `decoder`, one position
     per call; caches self K/V per block and the per-sentence cross K/V."""
 
     def __init__(self, W, cfg: GenConfig, enc_out: torch.Tensor):
@@ -440,7 +440,7 @@ def rollout_incremental(W, cfg, x, y, give_num: int, u_rg: np.ndarray, max_len: 
 
 def teacher_forced_logits(W, cfg, x, y_full) -> torch.Tensor:
     """Logits [B, T, V] of decoder(shift_right(y_full)) - used to check sampled tokens under
-    forced-identical prefixes (SURVEY §7 hard part ii)."""
+    forced-identical prefixes."""
     enc = encoder(W, cfg, x)
     return top(W, cfg, decoder(W, cfg, shift_right(y_full), enc))
 
@@ -456,7 +456,7 @@ def generate_step(W, cfg, x, max_len: int) -> np.ndarray:
     return cur.numpy().astype(np.int32)
 
 
-# --------------------------------------------------------------------------- policy-gradient step (SURVEY section 8f-3)
+# --------------------------------------------------------------------------- policy-gradient step
 def pg_loss(W, cfg: GenConfig, x, y, reward) -> torch.Tensor:
     """model.py:649-666 gan_output on decoder(shift_right(Y)) (model.py:178-184):
     g_loss = -sum_{b,t} softmax(logits)[b, t, Y[b,t]] * reward[b,t] / B   (probabilities, not log-probs)."""
@@ -555,7 +555,7 @@ def disc_forward(Wd, dcfg: DisConfig, input_x_TB: np.ndarray, input_xs_TB: np.nd
     return torch.softmax(scores, dim=1)                               # :508
 
 
-# --------------------------------------------------------------------------- discriminator training step (SURVEY section 8f-4)
+# --------------------------------------------------------------------------- discriminator training step
 BN_DECAY = 0.9                                    # conv_batch_norm(decay=0.9), cnn_discriminator.py:22
 DIS_TRAINABLE_SKIP = ("moving_mean", "moving_variance")
 
@@ -714,7 +714,7 @@ def get_reward(W, cfg, Wd, dcfg, x, x_to_maxlen, y_sample, y_sample_mask, rollnu
 # --------------------------------------------------------------------------- synthetic inputs
 def synthetic_batch(B: int, T: int, Vs: int, Vt: int, seed: int = 1234, eos_rows: Sequence[int] = (),
                     short_src_rows: Sequence[int] = ()):
-    """SURVEY §8d synthetic inputs: x = T-1 ids in [4,V) + </S>; y_sample ids in [4,V), no EOS
+    """Synthetic benchmark inputs: x = T-1 ids in [4,V) + </S>; y_sample ids in [4,V), no EOS
     (all rows full length) except `eos_rows`, which get an early </S>; `short_src_rows` get a
     shorter, zero-padded source."""
     rng = np.random.default_rng(seed)

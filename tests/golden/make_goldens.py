@@ -1,7 +1,7 @@
 """Regenerates tests/golden/tiny_v1.npz from the fp64 CPU oracle (oracle/nmtgan_oracle.py).
 
 The reference ships no tests, fixtures or golden vectors and cannot be run here (Python 2 +
-TensorFlow 1.2; SURVEY section 8c), so these vectors pin the ORACLE against regressions and give the
+TensorFlow 1.2), so these vectors pin the ORACLE against regressions and give the
 GPU tests a fixed target; they are NOT outputs of the reference ("parity unpinned").
 Weights are not stored: they are regenerated from the recorded seeds by oracle.init_*_weights
 (numpy PCG64 streams are stable across numpy versions).

@@ -44,7 +44,7 @@ def make_gpu_pair(gcfg, dcfg, Wg, Wd, precision, max_len):
 
 
 def rel_err(a, b):
-    """tensor-scale relative error ||a-b||_inf / ||b||_inf (SURVEY section 7 hard part iii)."""
+    """tensor-scale relative error ||a-b||_inf / ||b||_inf."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))

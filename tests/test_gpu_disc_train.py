@@ -1,4 +1,4 @@
-"""Discriminator training step (reference DisCNN.train / build_model / build_train_model,
+"""Discriminator training step ( reference DisCNN.train / build_model / build_train_model,
 cnn_discriminator.py:248-345, 561-591, 664-691) through the C ABI against the oracle's train-mode restatement
 (autograd in fp64 + gradient clip + RMSProp + moving-statistics update).  Parity unpinned like the rest of the
 path (no TensorFlow here); tolerances are written in each test."""

@@ -1,6 +1,6 @@
 """Full-size (BASELINE.json configs[1] = C2: d512 N6 h8, B64 R16 T50 V32000, fp16 tier) checks of the
 rollout-reward path through properties that do not need the oracle to replay 1.25 M sampled tokens
-(SURVEY section 8c/8d): determinism, prefix preservation, shard invariance (uniforms are addressed by
+(the oracle cannot replay them in seconds): determinism, prefix preservation, shard invariance (uniforms are addressed by
 global sentence id), range and masking of the rewards, the reward tail recomputed on the host in the
 reference's order (model.py:334-345), and oracle spot checks of the sampler (first sampled token of a
 rollout from the GPU's own prefix logits, full V) and of the discriminator (a few rollouts, fp64 CPU)."""

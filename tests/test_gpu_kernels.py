@@ -255,7 +255,7 @@ def _sample(L, logits, u, row_map=None, u_off=None, u_add=0, greedy=0, M=None):
 
 @pytest.mark.parametrize("V", [512, 32000, 34432])
 def test_sampler_matches_cdf_oracle(cuda, V):
-    """Known-answer test of the sampler against the fp64 CDF oracle (SURVEY A.5), including peaked
+    """Known-answer test of the sampler against the fp64 CDF oracle, including peaked
     rows, a row with one dominant logit, -inf entries and u at 0 / just below 1."""
     from oracle import nmtgan_oracle as O
     L = _lib()

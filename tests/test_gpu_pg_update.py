@@ -1,4 +1,4 @@
-"""Policy-gradient update of the generator (reference Model.generate_step_and_update,
+"""Policy-gradient update of the generator ( reference Model.generate_step_and_update,
 model.py:273-276, 178-190, 649-666) through the C ABI against the oracle's autograd (fp64) + RMSProp
 restatement.  Parity unpinned like the rest of the path (no TensorFlow here): the oracle is this repo's
 restatement; tolerances are written in each test."""

@@ -1,6 +1,6 @@
 """CPU tests of the oracle (test infrastructure): it must reproduce its committed golden vectors,
 its two decoding modes must agree, and its host helpers must behave like the reference's.
-The reference holds no fixtures for this path (SURVEY section 4): parity vs TensorFlow is UNPINNED."""
+The reference holds no fixtures for this path: parity vs TensorFlow is UNPINNED."""
 import os
 
 import numpy as np
@@ -42,7 +42,7 @@ def test_oracle_reproduces_golden_rewards_and_rollouts(gold, models):
 
 
 def test_structure_faithful_equals_incremental(gold, models):
-    """SURVEY A.4: KV-cached single-position decoding is result-identical to the reference's full
+    """KV-cached single-position decoding is result-identical to the reference's full
     re-decode per sampled token (one roll, three prefix lengths)."""
     gcfg, dcfg, W, Wd = models
     T = int(gold["T"])

@@ -1,4 +1,4 @@
-"""TF V2 checkpoint reader/writer (SURVEY section 8f-2) - CPU tests.
+"""TF V2 checkpoint reader/writer - CPU tests.
 
 Parity unpinned: neither TensorFlow nor a checkpoint written by it exists here or in the reference, so
 the format restatement is checked against (i) published CRC-32C known answers (RFC 3720 B.4), (ii) a
@@ -141,7 +141,7 @@ def test_round_trip_many_blocks_and_state_file(tmp_path):
 
 
 def test_facade_weight_dicts_survive_a_checkpoint(tmp_path):
-    """The synthetic generator + discriminator weight dicts (SURVEY Appendix C names) written as bundles and
+    """The synthetic generator + discriminator weight dicts written as bundles and
     read back are identical, so Model.init_and_restore(modelFile=prefix) / DisCNN(reload=True, saveto=prefix)
     see the arrays load_weights() was given."""
     from nmt_gan_amd import synthetic

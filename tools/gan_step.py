@@ -4,7 +4,7 @@ synthetic data, phase by phase with wall-clock times - every phase runs on the M
 
     python tools/gan_step.py [--config c2] [--iters 2] [--precision bf16]
 
-    x, y_ground            synthetic batch (SURVEY section 8d)
+    x, y_ground            synthetic batch
     y_sample               generator.generate_step(x)                                  gan_train.py:91
     y, mask                deal_generated_samples(y_sample)                            gan_train.py:93
     rewards                generator.get_reward(x, x_to_maxlen, y, mask, rollnum, D)   gan_train.py:102   <- the hot path
