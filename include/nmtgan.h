@@ -58,9 +58,14 @@ const char* nmtgan_last_error(void);
  * epilogue NMTGAN_EPI_CONVMAX: v = relu(acc*scale[n] + shift[n]) (conv bias + inference BN folded,
  *      cnn_discriminator.py:100-105,22-33); pooled[(r / a_group)*ld_pool + n] = max(., v) - the
  *      max over time of cnn_discriminator.py:469.  pooled must be >= 0 on entry (memset 0).
+ * epilogue NMTGAN_EPI_ADDLN  : ln_x <- LayerNorm(ln_x + acc + bias) * ln_gamma + ln_beta (eps 1e-6, biased
+ *      variance), also written to ln_out in the op dtype when ln_out != NULL: the residual() of model.py:725-739
+ *      fused into the projection that feeds it.  16-bit op dtypes, N = 512, plain rows, K*esize % 64 == 0.
+ *      ln_x is [M][512] fp32, read and rewritten in place; every row's result depends on that row alone.
  */
 #define NMTGAN_EPI_LINEAR 0
 #define NMTGAN_EPI_CONVMAX 1
+#define NMTGAN_EPI_ADDLN 2
 typedef struct {
   int op_dtype;              /* NMTGAN_BF16 / NMTGAN_F32 for A and Wt */
   int epilogue;
@@ -86,6 +91,11 @@ typedef struct {
   int64_t ld_pool;
   int64_t ldw;               /* elements per Wt row; 0 = K.  > K selects a column slice of a wider matrix (the taps
                                 [k, w) of a conv filter bank: Wt + k*E, K = (w-k)*E, ldw = w*E) */
+  /* ADDLN (bias as in LINEAR) */
+  float* ln_x;               /* [M][N] fp32, in and out */
+  const float* ln_gamma;     /* [N] */
+  const float* ln_beta;      /* [N] */
+  void* ln_out;              /* [M][N] op dtype or NULL */
 } nmtgan_gemm_args;
 int nmtgan_gemm(const nmtgan_gemm_args* a, void* stream);
 

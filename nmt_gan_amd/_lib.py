@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NMTGAN_LIB") or os.path.join(_HERE, "libnmtgan_hip.so")   # NMTGAN_LIB: another build of the same ABI
 
 NMTGAN_BF16, NMTGAN_F32, NMTGAN_F16 = 0, 1, 2
-EPI_LINEAR, EPI_CONVMAX = 0, 1
+EPI_LINEAR, EPI_CONVMAX, EPI_ADDLN = 0, 1, 2
 MAX_BLOCKS, MAX_WIDTHS = 16, 32
 
 vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
@@ -23,7 +23,8 @@ class GemmArgs(C.Structure):
                 ("lda", i64), ("a_group", i32), ("a_group_stride", i64),
                 ("bias", vp), ("relu", i32), ("n_seg", i32), ("seg_width", i32),
                 ("out", vp * 3), ("ldo", i64 * 3), ("out_f32", i32 * 3), ("seg_scale", f32 * 3),
-                ("scale", vp), ("shift", vp), ("pooled", vp), ("ld_pool", i64), ("ldw", i64)]
+                ("scale", vp), ("shift", vp), ("pooled", vp), ("ld_pool", i64), ("ldw", i64),
+                ("ln_x", vp), ("ln_gamma", vp), ("ln_beta", vp), ("ln_out", vp)]
 
 
 class EmbedArgs(C.Structure):

@@ -121,10 +121,6 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
 //    current one is consumed, so 2*KB*2 vector loads per wave are in flight across the softmax chain;
 //  - head reductions use DPP (quad_perm / row_half_mirror / row_mirror) instead of ds_bpermute;
 //  - scores are kept in log2 units (q pre-scaled by log2 e): every exponential is one v_exp_f32.
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
 __device__ __forceinline__ float head_sum(float v, int lph) {   // sum over the lph adjacent lanes of a head
   if (lph > 1) v = dpp_add<0xB1>(v);               // quad_perm [1,0,3,2]
   if (lph > 2) v = dpp_add<0x4E>(v);               // quad_perm [2,3,0,1]

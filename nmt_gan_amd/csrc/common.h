@@ -232,6 +232,13 @@ __device__ __forceinline__ float groups4_sum(float v) {
   u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// v + (v of the lane a DPP control selects): 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1]
+// (lane ^ 2), 0x141 = row_half_mirror (7 - lane inside 8 lanes), 0x140 = row_mirror (15 - lane inside 16 lanes);
+// applied in that order they sum over 2, 4, 8, 16 adjacent lanes without touching LDS
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -65,8 +65,10 @@ struct GemmParams {
   // split-K (gemm_glds_kernel, LINEAR epilogue): grid.y = split_k slices of the k-tiles, each leaves its raw fp32
   // partial in split_part[z][M][N]; splitk_finish_kernel adds the slices in order and applies the epilogue
   int split_k; float* split_part;
+  // add + LayerNorm epilogue (gemm_ln_kernel)
+  float* ln_x; const float* ln_gamma; const float* ln_beta; void* ln_out;
 };
-constexpr int EPI_STATS = 2;
+constexpr int EPI_STATS = 100;                  // internal: never a value of nmtgan_gemm_args.epilogue
 
 // acc[I0 + i][J0 + j] += A-fragment i x B-fragment j for one k-half of a k-tile (MT x NT 16x16 tiles).  Consecutive
 // MFMAs go to different accumulators, so the dependent-accumulator latency of the fp32 shape is never exposed.
@@ -838,6 +840,207 @@ static int launch_p8(GemmParams p, hipStream_t st) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ full-row kernel
+// x <- LayerNorm(x + A . Wt^T + bias) * gamma + beta for N = 512 and 16-bit operands: the residual add and the
+// normalisation of model.py:725-739 in the epilogue of the projection that feeds them, so the projection's fp32
+// output never goes to HBM and comes back (12 bytes per element of x instead of 20 for GEMM + add_layernorm).
+// A block tile spans whole rows: BM x 512, 8 waves side by side, wave w owns columns 64 w .. 64 w + 63 of all BM
+// rows (MT = BM / 16 row blocks x 4 column blocks of 16x16).  The column -> wave -> lane mapping and the order
+// of every sum do not depend on BM or on the tile a row falls in: a row's result is a function of that row alone.
+// k-tiles are 64 BYTES wide (one 16x16x32 MFMA k-step) so that three stages of the 576 / 640-row [A; W] image
+// fit (36 / 40 KiB each).  A DMA instruction writes 16 rows linearly; row r keeps logical 16-byte chunk c at
+// physical chunk c ^ ((r >> 2) & 3): the 16 rows a fragment read touches (r & 3 picks the 64-byte quarter of
+// the 256-byte bank line, (r >> 2) & 3 the swizzle) land on 16 different bank quads.
+// Same stream structure as gemm_pipe_kernel: persistent, loads two k-tiles ahead, counted vmcnt waits.
+constexpr int LBN = 512, LKB = 64, LSCR = 16 * 36 * 4;
+
+template <typename OpT, int BM>
+__global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
+  constexpr int MT = BM / 16, ROWS = BM + LBN, LSTAGE = ROWS * LKB, NUNIT = ROWS / 16, NI = (NUNIT + 7) / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x;
+  const int nkt = p.kbytes / LKB;                // >= 4 (launch guarantees it)
+  const int my_tiles = (p.ntm - (int)blockIdx.x + G - 1) / G;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
+  // the last of a wave's NI staging units exists for every wave only if NUNIT is a multiple of 8
+  const bool full = (NUNIT % 8 == 0) || wave + 8 * (NI - 1) < NUNIT;
+
+  const char* src[NI];
+  auto set_src = [&](int tile) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int rho = 16 * (wave + 8 * j) + (lane >> 2);
+      const int lc = (lane & 3) ^ ((rho >> 2) & 3);
+      if (rho < BM) src[j] = p.A + (int64_t)min(tile * BM + rho, p.M - 1) * p.lda_b + lc * 16;
+      else src[j] = p.W + (int64_t)min(rho - BM, LBN - 1) * p.ldw_b + lc * 16;
+    }
+  };
+  int is_buf = 0;
+  auto issue = [&]() {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (j < NI - 1 || full) glds16_m0(src[j], lds_base + is_buf * LSTAGE + (wave + 8 * j) * 1024);
+      src[j] += LKB;
+    }
+    is_buf = is_buf == 2 ? 0 : is_buf + 1;
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fc = lane & 15, fq = lane >> 4;
+  const int pc = (fq ^ ((fc >> 2) & 3)) << 4;
+  const int a_rd = fc * LKB + pc;
+  const int b_rd = (BM + wave * 64 + fc) * LKB + pc;
+  float* scr = reinterpret_cast<float*>(smem + 3 * LSTAGE + wave * LSCR);
+  float* stat0 = reinterpret_cast<float*>(smem + 3 * LSTAGE + 8 * LSCR);   // [BM][8] partial row sums per wave
+  float* stat1 = stat0 + BM * 8;
+
+#define NMTGAN_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  auto wait_stage = [&]() {                      // all but this wave's newest stage have landed
+    if (full) NMTGAN_WAIT(NI); else NMTGAN_WAIT(NI - 1);
+  };
+  int cbuf = 0;
+  auto step = [&](bool do_issue) {
+    __builtin_amdgcn_s_barrier();
+    if (do_issue) issue();
+    const unsigned char* base = smem + cbuf * LSTAGE;
+    uint4 fa[MT], fb[4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(base + a_rd + i * 16 * LKB);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(base + b_rd + j * 16 * LKB);
+    mma_block<OpT, MT, 4, 0, 0>(fa, fb, acc);
+    cbuf = cbuf == 2 ? 0 : cbuf + 1;
+  };
+
+  const int c4 = 4 * (lane & 7), rl = lane >> 3;   // row-major view of a 16 x 32 piece: row rl + 8 t, columns c4 .. c4 + 3
+  const int ncol = 64 * wave;
+  set_src((int)blockIdx.x);
+  issue();
+  issue();
+  for (int t = 0; t < my_tiles; ++t) {
+    const bool has_next = t + 1 < my_tiles;
+    for (int kt = 0; kt < nkt - 2; ++kt) {
+      wait_stage();
+      step(true);
+    }
+    if (has_next) set_src((int)blockIdx.x + (t + 1) * G);
+    wait_stage();
+    step(has_next);
+    if (has_next) wait_stage(); else NMTGAN_WAIT(0);
+    step(has_next);
+
+    // ---- epilogue: v = x + acc + bias in the row-major view, two-pass mean / variance over the 512 columns
+    const int m0 = ((int)blockIdx.x + t * G) * BM;
+    float4 vv[MT][2][2];
+    float bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias[j] = p.bias ? p.bias[ncol + 16 * j + fc] : 0.f;
+    // 64 rows at a time: all their residual loads go out first, then the accumulators are transposed through the
+    // per-wave scratch into the same row-major registers (accumulators and row-major values of at most 64 rows are
+    // live together)
+#pragma unroll
+    for (int h = 0; h < MT / 4; ++h) {
+#pragma unroll
+      for (int i = 4 * h; i < 4 * h + 4; ++i)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const int m = m0 + 16 * i + rl + 8 * tt;
+            vv[i][jp][tt] = m < p.M ? *reinterpret_cast<const float4*>(p.ln_x + (int64_t)m * LBN + ncol + 32 * jp + c4)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+      for (int i = 4 * h; i < 4 * h + 4; ++i)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) scr[(4 * fq + e) * 36 + 16 * jj + fc] = acc[i][2 * jp + jj][e] + bias[2 * jp + jj];
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const float4 x = *reinterpret_cast<const float4*>(scr + (rl + 8 * tt) * 36 + c4);
+            float4& v = vv[i][jp][tt];
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+          }
+        }
+      if (h + 1 < MT / 4) __builtin_amdgcn_sched_barrier(0);
+    }
+    // sum over a row: the lane's 8 values, the 8 lanes that share the row, then the 8 waves in wave order
+    auto row_total = [&](float s, float* stat, int row) {
+      s = dpp_add<0xB1>(s);
+      s = dpp_add<0x4E>(s);
+      s = dpp_add<0x141>(s);
+      if ((lane & 7) == 0) stat[row * 8 + wave] = s;
+    };
+    auto row_read = [&](const float* stat, int row) {
+      const float4 a = *reinterpret_cast<const float4*>(stat + row * 8);
+      const float4 b = *reinterpret_cast<const float4*>(stat + row * 8 + 4);
+      return ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+    };
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const float4 &u = vv[i][0][tt], &w = vv[i][1][tt];
+        row_total(((u.x + u.y) + (u.z + u.w)) + ((w.x + w.y) + (w.z + w.w)), stat0, 16 * i + rl + 8 * tt);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const float mean = row_read(stat0, 16 * i + rl + 8 * tt) * (1.0f / LBN);
+        float q = 0.f;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          float4& v = vv[i][jp][tt];
+          v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+          q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        row_total(q, stat1, 16 * i + rl + 8 * tt);
+      }
+    __syncthreads();
+    float4 gam[2], bet[2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      gam[jp] = *reinterpret_cast<const float4*>(p.ln_gamma + ncol + 32 * jp + c4);
+      bet[jp] = *reinterpret_cast<const float4*>(p.ln_beta + ncol + 32 * jp + c4);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int m = m0 + 16 * i + rl + 8 * tt;
+        const float rs = rsqrtf(row_read(stat1, 16 * i + rl + 8 * tt) * (1.0f / LBN) + 1e-6f);
+        if (m < p.M) {
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            const float4& v = vv[i][jp][tt];
+            float o[4] = {(v.x * rs) * gam[jp].x + bet[jp].x, (v.y * rs) * gam[jp].y + bet[jp].y,
+                          (v.z * rs) * gam[jp].z + bet[jp].z, (v.w * rs) * gam[jp].w + bet[jp].w};
+            const int64_t at = (int64_t)m * LBN + ncol + 32 * jp + c4;
+            *reinterpret_cast<float4*>(p.ln_x + at) = make_float4(o[0], o[1], o[2], o[3]);
+            if (p.ln_out) VecIO<OpT, 4>::store(reinterpret_cast<OpT*>(p.ln_out) + at, o);
+          }
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#undef NMTGAN_WAIT
+}
+
 // ------------------------------------------------------------------------------------------ generic kernel
 constexpr int GBM = 128, GBN = 128, GTILE = GBM * BKB;
 
@@ -938,6 +1141,11 @@ static int launch_glds(GemmParams p, hipStream_t st) {
 static thread_local float* g_splitk_buf = nullptr;
 static thread_local size_t g_splitk_bytes = 0;
 void set_gemm_splitk_scratch(void* buf, size_t bytes) { g_splitk_buf = (float*)buf; g_splitk_bytes = bytes; }
+bool gemm_splitk_active() { return g_splitk_buf != nullptr; }
+bool gemm_addln_supported(int op_dtype, int N, int K) {
+  const int es = dtype_size(op_dtype);
+  return es == 2 && N == LBN && (K * es) % LKB == 0 && (K * es) / LKB >= 4;
+}
 static int choose_split_k(const GemmParams& p, int nkt) {
   if (!g_splitk_buf) return 1;
   const int64_t tiles = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -962,6 +1170,35 @@ static int launch_generic(GemmParams p, hipStream_t st) {
   hipLaunchKernelGGL((gemm_kernel<OpT, EPI>), dim3(p.ntm * p.ntn), dim3(256), 4 * GTILE, st, p);
   NMTGAN_CHECK_LAUNCH("gemm");
   return 0;
+}
+
+template <typename OpT, int BM>
+static int launch_ln(GemmParams p, hipStream_t st) {
+  constexpr int smem = 3 * (BM + LBN) * LKB + 8 * LSCR + 2 * BM * 8 * (int)sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_kernel<OpT, BM>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      NMTGAN_FAIL(-3, "gemm: cannot raise dynamic LDS limit");
+    attr_done = true;
+  }
+  p.ntm = (p.M + BM - 1) / BM;
+  p.ntn = 1;
+  hipLaunchKernelGGL((gemm_ln_kernel<OpT, BM>), dim3(persistent_grid(p.ntm)), dim3(512), smem, st, p);
+  NMTGAN_CHECK_LAUNCH("gemm_ln");
+  return 0;
+}
+// 64-row tiles.  (BM = 128 is a third less LDS and L2 traffic per flop but its epilogue holds 128 accumulator and
+// up to 128 row-major registers per lane and spills; NMTGAN_LN_BM=128 selects it for experiments - the results
+// are the same bits either way.)
+template <typename OpT>
+static int dispatch_ln(const GemmParams& p, hipStream_t st) {
+  static const int force = [] { const char* e = getenv("NMTGAN_LN_BM"); return e ? atoi(e) : 0; }();
+  if constexpr (sizeof(OpT) == 2) {
+    if (force == 128) return launch_ln<OpT, 128>(p, st);
+    return launch_ln<OpT, 64>(p, st);
+  }
+  NMTGAN_FAIL(-2, "gemm: the ADDLN epilogue needs a 16-bit op dtype");
 }
 
 static int tile_override() {        // NMTGAN_GEMM_TILE=128|256|0(generic) for experiments; unset = heuristic
@@ -991,7 +1228,6 @@ static bool prefer_p8(int64_t M, int N, int nkt) {
   const double t_p8 = (double)((N + 255) / 256 * 256) / 1250.0, t_pipe = (double)((N + 127) / 128 * 128) / 1080.0;
   return t_p8 < t_pipe;
 }
-
 template <typename OpT, int EPI>
 static int dispatch(const GemmParams& p, hipStream_t st) {
   const int ov = tile_override();
@@ -1118,6 +1354,16 @@ static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
     NMTGAN_REQUIRE(a->scale && a->shift && a->pooled, "gemm: CONVMAX needs scale/shift/pooled");
     p.scale = a->scale; p.shift = a->shift; p.pooled = a->pooled; p.ld_pool = a->ld_pool;
     NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch<OpT, NMTGAN_EPI_CONVMAX>(p, st));
+  }
+  if (a->epilogue == NMTGAN_EPI_ADDLN) {
+    NMTGAN_REQUIRE(gemm_addln_supported(a->op_dtype, a->N, a->K),
+                   "gemm: ADDLN needs a 16-bit op dtype, N = 512 and K*esize a multiple of 64 bytes, >= 256 (N=%d K=%d)", a->N, a->K);
+    NMTGAN_REQUIRE(a->a_group <= 0, "gemm: ADDLN takes plain rows (a_group = 0)");
+    NMTGAN_REQUIRE(a->ln_x && a->ln_gamma && a->ln_beta, "gemm: ADDLN needs ln_x / ln_gamma / ln_beta");
+    NMTGAN_REQUIRE((uintptr_t)a->ln_x % 16 == 0 && (uintptr_t)a->ln_gamma % 16 == 0 && (uintptr_t)a->ln_beta % 16 == 0 &&
+                       (uintptr_t)a->ln_out % 8 == 0, "gemm: ADDLN pointers misaligned");
+    p.bias = a->bias; p.ln_x = a->ln_x; p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_out = a->ln_out;
+    NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch_ln<OpT>(p, st));
   }
   NMTGAN_FAIL(-2, "gemm: unknown epilogue %d", a->epilogue);
 }

@@ -15,6 +15,9 @@ void set_gemm_wg_cap(int cap);
 // split-K scratch of the calling thread for the small LINEAR GEMMs (nullptr = off, the default); a pipeline that
 // issues all its GEMMs on ONE stream sets it around its launches
 void set_gemm_splitk_scratch(void* buf, size_t bytes);
+bool gemm_splitk_active();
+// shapes the NMTGAN_EPI_ADDLN epilogue (projection + residual + LayerNorm in one kernel) takes
+bool gemm_addln_supported(int op_dtype, int N, int K);
 struct SplitKScope {
   SplitKScope(void* buf, size_t bytes) { set_gemm_splitk_scratch(buf, bytes); }
   ~SplitKScope() { set_gemm_splitk_scratch(nullptr, 0); }

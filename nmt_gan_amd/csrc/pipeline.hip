@@ -46,6 +46,26 @@ static int add_ln(const nmtgan_generator* g, float* xf, const float* yf, const n
   return launch_add_layernorm(&a, st);
 }
 
+// xf <- LayerNorm(xf + A . w^T + b), xo = its op-dtype copy: one kernel where the fused epilogue takes the shape
+// (16-bit tiers at d = 512) and the projection is bound by its output traffic (K <= d: the attention output
+// projections), else the projection into yf followed by add_layernorm (K = 4 d, the second feed-forward layer, is
+// bound by the matrix cores and runs faster on the 256x256 kernel even with the extra round trip of yf;
+// NMTGAN_FUSE_LN=2 fuses it too, 0 fuses nothing).  The split-K pipelines (B-row greedy decode) keep the two-kernel
+// form: their projections are cut into k-slices to fill the CUs.
+static int dense_add_ln(const nmtgan_generator* g, const void* A, int64_t lda, int M, int K, const nmtgan_dense& w,
+                        const nmtgan_ln& ln, float* xf, float* yf, void* xo, hipStream_t st) {
+  static const int fuse = [] { const char* e = getenv("NMTGAN_FUSE_LN"); return e ? atoi(e) : 1; }();
+  if (fuse > 0 && (K <= g->d || fuse > 1) && !gemm_splitk_active() && gemm_addln_supported(g->op_dtype, g->d, K)) {
+    nmtgan_gemm_args a{};
+    a.op_dtype = g->op_dtype; a.epilogue = NMTGAN_EPI_ADDLN;
+    a.A = A; a.Wt = w.w; a.M = M; a.N = g->d; a.K = K; a.lda = lda;
+    a.bias = w.b; a.ln_x = xf; a.ln_gamma = ln.g; a.ln_beta = ln.b; a.ln_out = xo;
+    return launch_gemm(&a, st);
+  }
+  NMTGAN_TRY(dense1(g->op_dtype, A, lda, M, K, g->d, w, yf, g->d, 1, 1.f, 0, st));
+  return add_ln(g, xf, yf, ln, M, xo, nullptr, st);
+}
+
 static int check_generator(const nmtgan_generator* g) {
   NMTGAN_REQUIRE(g != nullptr, "generator: null");
   NMTGAN_REQUIRE(valid_op_dtype(g->op_dtype), "generator: bad op_dtype");
@@ -179,8 +199,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       prof::Hint ph(c.step_mode ? prof::ATTN_SELF : prof::ATTN_PREFILL);
       NMTGAN_TRY(launch_attn_rows(&t, st));
     }
-    NMTGAN_TRY(dense1(op, a.ao, d, M, d, d, b.o, a.yf, d, 1, 1.f, 0, st));
-    NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln0, M, a.xo, nullptr, st));
+    NMTGAN_TRY(dense_add_ln(g, a.ao, d, M, d, b.o, b.ln0, a.xf, a.yf, a.xo, st));
     NMTGAN_TRY(dense1(op, a.xo, d, M, d, d, b.cq, a.q, d, 0, qscale, 0, st));
     if (c.group_R > 0) {
       nmtgan_attn_group_args ga{};
@@ -199,14 +218,12 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       prof::Hint ph(c.step_mode ? prof::ATTN_CROSS : prof::ATTN_PREFILL);
       NMTGAN_TRY(launch_attn_rows(&t, st));
     }
-    NMTGAN_TRY(dense1(op, a.ao, d, M, d, d, b.co, a.yf, d, 1, 1.f, 0, st));
-    NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln1, M, a.xo, nullptr, st));
+    NMTGAN_TRY(dense_add_ln(g, a.ao, d, M, d, b.co, b.ln1, a.xf, a.yf, a.xo, st));
     {
       prof::Hint ph(prof::GEMM_FFN);
       NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
-      NMTGAN_TRY(dense1(op, a.h, 4 * d, M, 4 * d, d, b.ffn2, a.yf, d, 1, 1.f, 0, st));
+      NMTGAN_TRY(dense_add_ln(g, a.h, 4 * d, M, 4 * d, b.ffn2, b.ln2, a.xf, a.yf, a.xo, st));
     }
-    NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln2, M, a.xo, nullptr, st));
   }
   return 0;
 }

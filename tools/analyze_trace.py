@@ -24,7 +24,7 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     t = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r) for r in rows]
     # last step: starts at the second-to-last... find embed kernels; a step = [encoder embed ... reward_reduce]
-    ends = [i for i, x in enumerate(t) if x[0].startswith("reward_reduce_kernel")]
+    ends = [i for i, x in enumerate(t) if "reward_reduce_kernel" in x[0]]
     if len(ends) >= 2:
         t = t[ends[-2] + 1: ends[-1] + 1]
     tot = defaultdict(lambda: [0, 0.0])
@@ -44,5 +44,28 @@ def main():
                 print("%6d %9.1f us grid %s wg %s  %s" % (i, (e - s) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", "?"), n[:100]))
 
 
+def per_step():
+    """--steps: wall / busy time and dispatch count of every rollout step (cut at the step's embed kernel), with the
+    rows of the step read off the embed grid (4 rows per 256-thread workgroup)"""
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    t = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r) for r in rows]
+    ends = [i for i, x in enumerate(t) if "reward_reduce_kernel" in x[0]]
+    if len(ends) >= 2:
+        t = t[ends[-2] + 1: ends[-1] + 1]
+    cuts = [i for i, x in enumerate(t) if "embed_kernel" in x[0] and "disc_embed" not in x[0]]
+    cuts.append(len(t))
+    print("  seg   rows~   wall_us   busy_us  launches  gap_us/launch")
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        seg = t[a:b]
+        wall = ((t[b][1] if b < len(t) else seg[-1][2]) - seg[0][1]) / 1e3
+        busy = sum(e - s for _, s, e, _ in seg) / 1e3
+        g = int(seg[0][3].get("Grid_Size_X", seg[0][3].get("Grid_Size", 0))) // 256 * 4
+        print("%5d %7d %9.1f %9.1f %8d %10.2f" % (a, g, wall, busy, len(seg), (wall - busy) / len(seg)))
+
+
 if __name__ == "__main__":
-    main()
+    if "--steps" in sys.argv:
+        per_step()
+    else:
+        main()

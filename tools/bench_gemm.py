@@ -103,6 +103,54 @@ def run(name, M, N, K, conv, out_f32, iters=10):
     print("%-28s %8.3f ms  %7.1f TFLOP/s%s" % (name, ms, 2.0 * M * N * K / ms / 1e9, ref), flush=True)
 
 
+def run_addln(M, K, iters=10):
+    """projection + residual + LayerNorm (N = 512): the fused epilogue against GEMM (fp32 out) + add_layernorm"""
+    N = 512
+    g = torch.Generator(device=dev).manual_seed(2)
+    A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(TDT)
+    W = ((torch.rand(N, K, device=dev, generator=g) * 2 - 1) * (3.0 / K) ** 0.5).to(TDT)
+    bias = torch.zeros(N, device=dev); gamma = torch.ones(N, device=dev); beta = torch.zeros(N, device=dev)
+    x = torch.randn(M, N, device=dev, generator=g); y = torch.empty(M, N, device=dev); xo = torch.empty(M, N, device=dev, dtype=TDT)
+    f = L.GemmArgs()
+    f.op_dtype, f.epilogue, f.A, f.Wt, f.M, f.N, f.K, f.lda = OPC, L.EPI_ADDLN, A.data_ptr(), W.data_ptr(), M, N, K, K
+    f.bias, f.ln_x, f.ln_gamma, f.ln_beta, f.ln_out = bias.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), xo.data_ptr()
+    a = L.GemmArgs()
+    a.op_dtype, a.epilogue, a.A, a.Wt, a.M, a.N, a.K, a.lda = OPC, L.EPI_LINEAR, A.data_ptr(), W.data_ptr(), M, N, K, K
+    a.bias, a.n_seg, a.seg_width = bias.data_ptr(), 1, N
+    a.out[0], a.ldo[0], a.out_f32[0], a.seg_scale[0] = y.data_ptr(), N, 1, 1.0
+    n = L.AddLnArgs()
+    n.x, n.y, n.gamma, n.beta, n.M, n.d = x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, N
+    n.out_f32, n.out_op, n.op_dtype = x.data_ptr(), xo.data_ptr(), OPC
+    st = L.stream_ptr()
+
+    def fused():
+        L.check(L.lib.nmtgan_gemm(C.byref(f), st))
+
+    def split():
+        L.check(L.lib.nmtgan_gemm(C.byref(a), st))
+        L.check(L.lib.nmtgan_add_layernorm(C.byref(n), st))
+
+    ms = []
+    for fn in (fused, split):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1) / iters)
+    gb = M * N * (10 + 2.0 * K / N) / 1e9        # x in/out fp32 + op-dtype copy + A
+    print("addln  M%-6d K%-5d fused %8.3f ms (%6.2f TB/s of its 10 B/elt + A)   gemm + add_layernorm %8.3f ms"
+          % (M, K, ms[0], gb / ms[0], ms[1]), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "addln":
+        for M in (1024, 4096, 8192, 16384, 32768, 49152):
+            for K in (512, 2048):
+                run_addln(M, K)
+        sys.exit(0)
     for s in SHAPES:
         run(*s)
