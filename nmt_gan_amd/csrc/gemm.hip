@@ -589,6 +589,14 @@ __device__ __forceinline__ void glds16_m0(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 
+// same with a uniform 64-bit base in scalar registers and a 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory", "m0");
+}
+
 template <typename OpT, int EPI>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -856,7 +864,9 @@ constexpr int LBN = 512, LKB = 64, LSCR = 16 * 36 * 4;
 
 template <typename OpT, int BM>
 __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
-  constexpr int MT = BM / 16, ROWS = BM + LBN, LSTAGE = ROWS * LKB, NUNIT = ROWS / 16, NI = (NUNIT + 7) / 8;
+  // a stage holds NI * 8 DMA units of 16 rows; with BM = 64 the last four only pad the count to a multiple of the
+  // 8 waves (they re-fetch W rows into LDS nobody reads), so every wave runs the same counted waits
+  constexpr int MT = BM / 16, ROWS = BM + LBN, NI = (ROWS / 16 + 7) / 8, NUNIT = NI * 8, LSTAGE = NUNIT * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -864,27 +874,46 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
   const int nkt = p.kbytes / LKB;                // >= 4 (launch guarantees it)
   const int my_tiles = (p.ntm - (int)blockIdx.x + G - 1) / G;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
-  // the last of a wave's NI staging units exists for every wave only if NUNIT is a multiple of 8
-  const bool full = (NUNIT % 8 == 0) || wave + 8 * (NI - 1) < NUNIT;
+  constexpr bool full = true;
 
-  const char* src[NI];
+  // DMA sources = uniform base (A tile or W, advanced along k by scalar adds) + a 32-bit per-lane offset: unit
+  // wave + 8 j of the stacked [A; W] image holds rows 16 (wave + 8 j) .. + 15.  Only unit j = 0 can be an A unit
+  // (BM / 16 <= 8); its offsets change with the tile (rows past M re-read row M - 1), the W offsets never do.
+  const bool u0_is_a = wave < BM / 16;
+  const int lc0 = (lane & 3) ^ ((lane >> 4) & 3);                  // (rho >> 2) & 3 == (lane >> 4) & 3: units start at multiples of 16
+  unsigned voff[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int wrow = 16 * (wave + 8 * j) + (lane >> 2) - BM;       // W row of this lane in unit j (padding units clamp)
+    voff[j] = (unsigned)(min(max(wrow, 0), LBN - 1) * (int)p.ldw_b + lc0 * 16);
+  }
+  const char* a_base = p.A;
   auto set_src = [&](int tile) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int rho = 16 * (wave + 8 * j) + (lane >> 2);
-      const int lc = (lane & 3) ^ ((rho >> 2) & 3);
-      if (rho < BM) src[j] = p.A + (int64_t)min(tile * BM + rho, p.M - 1) * p.lda_b + lc * 16;
-      else src[j] = p.W + (int64_t)min(rho - BM, LBN - 1) * p.ldw_b + lc * 16;
+    if (u0_is_a) {
+      const int r = min(tile * BM + 16 * wave + (lane >> 2), p.M - 1) - tile * BM;
+      voff[0] = (unsigned)(r * (int)p.lda_b + lc0 * 16);
     }
+    a_base = p.A + (int64_t)tile * BM * p.lda_b;
   };
-  int is_buf = 0;
-  auto issue = [&]() {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      if (j < NI - 1 || full) glds16_m0(src[j], lds_base + is_buf * LSTAGE + (wave + 8 * j) * 1024);
-      src[j] += LKB;
+  // The (tile, k-step) pairs of the block form ONE stream of `total` k-steps; stage q of the stream lives in LDS buffer
+  // q % 3.  issue_next() sends the DMA of the next stage that has not been requested yet.
+  const int total = my_tiles * nkt;
+  int issued = 0, iss_k = 0, iss_t = 0, is_buf = 0;
+  auto issue_next = [&]() {
+    if (iss_k == nkt) {
+      iss_k = 0;
+      iss_t += 1;
+      set_src((int)blockIdx.x + iss_t * G);
     }
+    const char* wk = p.W + iss_k * LKB;
+    const char* ak = a_base + iss_k * LKB;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      glds16_s(voff[j], (j == 0 && u0_is_a) ? ak : wk,
+               __builtin_amdgcn_readfirstlane(lds_base + is_buf * LSTAGE + (wave + 8 * j) * 1024));
     is_buf = is_buf == 2 ? 0 : is_buf + 1;
+    iss_k += 1;
+    issued += 1;
   };
 
   f32x4 acc[MT][4];
@@ -900,88 +929,90 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
   float* scr = reinterpret_cast<float*>(smem + 3 * LSTAGE + wave * LSCR);
   float* stat0 = reinterpret_cast<float*>(smem + 3 * LSTAGE + 8 * LSCR);   // [BM][8] partial row sums per wave
   float* stat1 = stat0 + BM * 8;
+  float* red0 = stat1 + BM * 8;                    // [BM] row means, [BM] reciprocal deviations
+  float* red1 = red0 + BM;
 
 #define NMTGAN_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
   auto wait_stage = [&]() {                      // all but this wave's newest stage have landed
     if (full) NMTGAN_WAIT(NI); else NMTGAN_WAIT(NI - 1);
   };
-  int cbuf = 0;
-  auto step = [&](bool do_issue) {
-    __builtin_amdgcn_s_barrier();
-    if (do_issue) issue();
-    const unsigned char* base = smem + cbuf * LSTAGE;
-    uint4 fa[MT], fb[4];
+  // Fragments are double-buffered in registers: k-step q multiplies the fragments read during k-step q - 1 while the
+  // fragments of q + 1 are read from the stage that has just landed, so a wave's LDS reads run under its own MFMAs.
+  // Per k-step: wait (stage q + 1 landed, q + 2 may be in flight) -> this wave's reads of stage q are complete ->
+  // barrier (every wave is past its reads of stage q, whose buffer the DMA of stage q + 3 refills) -> issue q + 3
+  // -> read q + 1 -> 16 MFMAs of q.
+  uint4 fa[2][MT], fb[2][4];
+  auto read_frags = [&](int buf, uint4 (&a)[MT], uint4 (&b)[4]) {
+    const unsigned char* base = smem + buf * LSTAGE;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(base + a_rd + i * 16 * LKB);
+    for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(base + a_rd + i * 16 * LKB);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(base + b_rd + j * 16 * LKB);
-    mma_block<OpT, MT, 4, 0, 0>(fa, fb, acc);
-    cbuf = cbuf == 2 ? 0 : cbuf + 1;
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const uint4*>(base + b_rd + j * 16 * LKB);
   };
 
-  const int c4 = 4 * (lane & 7), rl = lane >> 3;   // row-major view of a 16 x 32 piece: row rl + 8 t, columns c4 .. c4 + 3
+  // row-major view of a 16 x 32 piece in the epilogue: row rl + 8 t, columns c4 .. c4 + 3 (rl = lane >> 3, c4 = 4 * (lane & 7))
   const int ncol = 64 * wave;
-  set_src((int)blockIdx.x);
-  issue();
-  issue();
-  for (int t = 0; t < my_tiles; ++t) {
-    const bool has_next = t + 1 < my_tiles;
-    for (int kt = 0; kt < nkt - 2; ++kt) {
-      wait_stage();
-      step(true);
-    }
-    if (has_next) set_src((int)blockIdx.x + (t + 1) * G);
-    wait_stage();
-    step(has_next);
-    if (has_next) wait_stage(); else NMTGAN_WAIT(0);
-    step(has_next);
-
-    // ---- epilogue: v = x + acc + bias in the row-major view, two-pass mean / variance over the 512 columns
+  int rbuf = 0;                                    // LDS buffer of the next stage whose fragments have not been read
+  auto epilogue_ln = [&](int t) {
+    // lane-derived indices are recomputed here from a value the optimiser cannot see through: otherwise it hoists the
+    // ~50 loop-invariant offsets of the epilogue out of the k-step loop and spills them
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int fc = lane_e & 15, fq = lane_e >> 4, c4 = 4 * (lane_e & 7), rl = lane_e >> 3;
+    // ---- epilogue.  The accumulators stay where the MFMAs left them (16x16 C layout: column = lane & 15, row =
+    // 4 * (lane >> 4) + e) from the residual add to the normalised value; only the global loads and stores use the
+    // row-major view (16 bytes per lane, whole 128-byte row segments per instruction), and each 16 x 32 piece
+    // changes view through the wave's LDS scratch.  Register peak: the accumulators plus one set of residual loads.
+    // addresses = one uniform tile base + a 32-bit lane offset (a 64-bit address per access would cost two registers each)
     const int m0 = ((int)blockIdx.x + t * G) * BM;
-    float4 vv[MT][2][2];
+    const int rows_here = min(BM, p.M - m0);
+    float* xt = p.ln_x + (int64_t)m0 * LBN;
+    OpT* ot = p.ln_out ? reinterpret_cast<OpT*>(p.ln_out) + (int64_t)m0 * LBN : nullptr;
+    const int col = ncol + c4;
     float bias[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bias[j] = p.bias ? p.bias[ncol + 16 * j + fc] : 0.f;
-    // 64 rows at a time: all their residual loads go out first, then the accumulators are transposed through the
-    // per-wave scratch into the same row-major registers (accumulators and row-major values of at most 64 rows are
-    // live together)
+    // the residual loads of the tile's 64 rows go out together, then each 16 x 32 piece changes view
+    constexpr int GI = 4;
+    auto add_residual = [&](auto H) {
+      constexpr int h = decltype(H)::value;
+      f32x4 res[GI][2][2];
 #pragma unroll
-    for (int h = 0; h < MT / 4; ++h) {
-#pragma unroll
-      for (int i = 4 * h; i < 4 * h + 4; ++i)
+      for (int i = 0; i < GI; ++i)
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            const int m = m0 + 16 * i + rl + 8 * tt;
-            vv[i][jp][tt] = m < p.M ? *reinterpret_cast<const float4*>(p.ln_x + (int64_t)m * LBN + ncol + 32 * jp + c4)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int tt = 0; tt < 2; ++tt) {           // rows past M re-read the last row: no predicate, no branch
+            const unsigned off = (unsigned)(min(16 * (GI * h + i) + rl + 8 * tt, rows_here - 1) * LBN + col + 32 * jp);
+            res[i][jp][tt] = *reinterpret_cast<const f32x4*>(xt + off);
           }
 #pragma unroll
-      for (int i = 4 * h; i < 4 * h + 4; ++i)
+      for (int i = 0; i < GI; ++i)
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
 #pragma unroll
+          for (int tt = 0; tt < 2; ++tt) *reinterpret_cast<f32x4*>(scr + (rl + 8 * tt) * 36 + c4) = res[i][jp][tt];
+#pragma unroll
           for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) scr[(4 * fq + e) * 36 + 16 * jj + fc] = acc[i][2 * jp + jj][e] + bias[2 * jp + jj];
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            const float4 x = *reinterpret_cast<const float4*>(scr + (rl + 8 * tt) * 36 + c4);
-            float4& v = vv[i][jp][tt];
-            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-          }
-        }
-      if (h + 1 < MT / 4) __builtin_amdgcn_sched_barrier(0);
-    }
-    // sum over a row: the lane's 8 values, the 8 lanes that share the row, then the 8 waves in wave order
+            for (int e = 0; e < 4; ++e)
+              acc[GI * h + i][2 * jp + jj][e] =
+                  scr[(4 * fq + e) * 36 + 16 * jj + fc] + (acc[GI * h + i][2 * jp + jj][e] + bias[2 * jp + jj]);
+          __builtin_amdgcn_sched_barrier(0);       // piece by piece: the scheduler otherwise gathers every piece's
+        }                                          // LDS reads in front of the adds and spills them
+    };
+    add_residual(std::integral_constant<int, 0>{});
+    static_assert(MT == 4, "one residual group per tile");
+    // sum over a row: the lane's 4 columns, the 16 lanes of the row's group, then the 8 waves in wave order by ONE
+    // thread per row, which leaves the row's mean / reciprocal deviation in red[row] for every wave to pick up
     auto row_total = [&](float s, float* stat, int row) {
       s = dpp_add<0xB1>(s);
       s = dpp_add<0x4E>(s);
       s = dpp_add<0x141>(s);
-      if ((lane & 7) == 0) stat[row * 8 + wave] = s;
+      s = dpp_add<0x140>(s);
+      if (fc == 0) stat[row * 8 + wave] = s;
     };
-    auto row_read = [&](const float* stat, int row) {
+    auto row_sum8 = [&](const float* stat, int row) {
       const float4 a = *reinterpret_cast<const float4*>(stat + row * 8);
       const float4 b = *reinterpret_cast<const float4*>(stat + row * 8 + 4);
       return ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
@@ -989,54 +1020,101 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const float4 &u = vv[i][0][tt], &w = vv[i][1][tt];
-        row_total(((u.x + u.y) + (u.z + u.w)) + ((w.x + w.y) + (w.z + w.w)), stat0, 16 * i + rl + 8 * tt);
+      for (int e = 0; e < 4; ++e) {
+        row_total((acc[i][0][e] + acc[i][1][e]) + (acc[i][2][e] + acc[i][3][e]), stat0, 16 * i + 4 * fq + e);
       }
+    __syncthreads();
+    if (tid < BM) red0[tid] = row_sum8(stat0, tid) * (1.0f / LBN);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const float mean = row_read(stat0, 16 * i + rl + 8 * tt) * (1.0f / LBN);
+      for (int e = 0; e < 4; ++e) {
+        const float mean = red0[16 * i + 4 * fq + e];
         float q = 0.f;
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          float4& v = vv[i][jp][tt];
-          v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-          q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j][e] -= mean;
+          q += acc[i][j][e] * acc[i][j][e];
         }
-        row_total(q, stat1, 16 * i + rl + 8 * tt);
+        row_total(q, stat1, 16 * i + 4 * fq + e);
       }
     __syncthreads();
-    float4 gam[2], bet[2];
+    if (tid < BM) red1[tid] = rsqrtf(row_sum8(stat1, tid) * (1.0f / LBN) + 1e-6f);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float rs = red1[16 * i + 4 * fq + e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j][e] *= rs;
+      }
+    f32x4 gam[2], bet[2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      gam[jp] = *reinterpret_cast<const float4*>(p.ln_gamma + ncol + 32 * jp + c4);
-      bet[jp] = *reinterpret_cast<const float4*>(p.ln_beta + ncol + 32 * jp + c4);
+      gam[jp] = *reinterpret_cast<const f32x4*>(p.ln_gamma + ncol + 32 * jp + c4);
+      bet[jp] = *reinterpret_cast<const f32x4*>(p.ln_beta + ncol + 32 * jp + c4);
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int m = m0 + 16 * i + rl + 8 * tt;
-        const float rs = rsqrtf(row_read(stat1, 16 * i + rl + 8 * tt) * (1.0f / LBN) + 1e-6f);
-        if (m < p.M) {
+      for (int jp = 0; jp < 2; ++jp) {
 #pragma unroll
-          for (int jp = 0; jp < 2; ++jp) {
-            const float4& v = vv[i][jp][tt];
-            float o[4] = {(v.x * rs) * gam[jp].x + bet[jp].x, (v.y * rs) * gam[jp].y + bet[jp].y,
-                          (v.z * rs) * gam[jp].z + bet[jp].z, (v.w * rs) * gam[jp].w + bet[jp].w};
-            const int64_t at = (int64_t)m * LBN + ncol + 32 * jp + c4;
-            *reinterpret_cast<float4*>(p.ln_x + at) = make_float4(o[0], o[1], o[2], o[3]);
-            if (p.ln_out) VecIO<OpT, 4>::store(reinterpret_cast<OpT*>(p.ln_out) + at, o);
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) scr[(4 * fq + e) * 36 + 16 * jj + fc] = acc[i][2 * jp + jj][e];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int r = 16 * i + rl + 8 * tt;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(scr + (rl + 8 * tt) * 36 + c4);
+          if (r < rows_here) {
+            const f32x4 o = v * gam[jp] + bet[jp];
+            const unsigned off = (unsigned)(r * LBN + col + 32 * jp);
+            *reinterpret_cast<f32x4*>(xt + off) = o;
+            if (ot)
+              *reinterpret_cast<uint2*>(ot + off) = make_uint2(Pack16<OpT>::pack2(o[0], o[1]), Pack16<OpT>::pack2(o[2], o[3]));
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto kstep = [&](int q, const uint4 (&ca)[MT], const uint4 (&cb)[4], uint4 (&na)[MT], uint4 (&nb)[4], bool read_next) {
+    if (q + 1 < total) {
+      if (q + 2 < issued) wait_stage(); else NMTGAN_WAIT(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (issued < total) issue_next();
+    if (read_next) {
+      read_frags(rbuf, na, nb);
+      rbuf = rbuf == 2 ? 0 : rbuf + 1;
+    }
+    mma_block<OpT, MT, 4, 0, 0>(ca, cb, acc);
+  };
+  set_src((int)blockIdx.x);
+  issue_next();
+  issue_next();
+  issue_next();
+  NMTGAN_WAIT(2 * NI);
+  __builtin_amdgcn_s_barrier();
+  int q = 0;
+  for (int t = 0; t < my_tiles; ++t) {
+    // the tile's first fragments are read here and not under the previous tile's last MFMAs: nothing but the
+    // accumulators stays live across the epilogue
+    read_frags(rbuf, fa[0], fb[0]);
+    rbuf = rbuf == 2 ? 0 : rbuf + 1;
+#pragma unroll 1
+    for (int kp = 0; kp < nkt / 2; ++kp) {         // nkt is even (launch guarantees it)
+      kstep(q, fa[0], fb[0], fa[1], fb[1], true);
+      kstep(q + 1, fa[1], fb[1], fa[0], fb[0], kp + 1 < nkt / 2);
+      q += 2;
+    }
+    epilogue_ln(t);
   }
 #undef NMTGAN_WAIT
 }
@@ -1144,7 +1222,7 @@ void set_gemm_splitk_scratch(void* buf, size_t bytes) { g_splitk_buf = (float*)b
 bool gemm_splitk_active() { return g_splitk_buf != nullptr; }
 bool gemm_addln_supported(int op_dtype, int N, int K) {
   const int es = dtype_size(op_dtype);
-  return es == 2 && N == LBN && (K * es) % LKB == 0 && (K * es) / LKB >= 4;
+  return es == 2 && N == LBN && (K * es) % (2 * LKB) == 0 && (K * es) / LKB >= 4;   // an even number of 64-byte k-steps
 }
 static int choose_split_k(const GemmParams& p, int nkt) {
   if (!g_splitk_buf) return 1;
@@ -1174,7 +1252,8 @@ static int launch_generic(GemmParams p, hipStream_t st) {
 
 template <typename OpT, int BM>
 static int launch_ln(GemmParams p, hipStream_t st) {
-  constexpr int smem = 3 * (BM + LBN) * LKB + 8 * LSCR + 2 * BM * 8 * (int)sizeof(float);
+  // three stages (each padded to a multiple of 8 DMA units of 1 KiB), per-wave scratch, two [BM][8] + two [BM] statistics arrays
+  constexpr int smem = 3 * (((BM + LBN) / 16 + 7) / 8 * 8) * 1024 + 8 * LSCR + (2 * BM * 8 + 2 * BM) * (int)sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_kernel<OpT, BM>),
@@ -1188,16 +1267,12 @@ static int launch_ln(GemmParams p, hipStream_t st) {
   NMTGAN_CHECK_LAUNCH("gemm_ln");
   return 0;
 }
-// 64-row tiles.  (BM = 128 is a third less LDS and L2 traffic per flop but its epilogue holds 128 accumulator and
-// up to 128 row-major registers per lane and spills; NMTGAN_LN_BM=128 selects it for experiments - the results
-// are the same bits either way.)
+// 64-row tiles only: a 128-row tile would halve the L2 -> LDS traffic per flop (the 512 W rows are re-fetched per
+// tile: 34 KB per MMAC against 16-23 for the plain kernels, which is what bounds this kernel at K = 2048), but its 128
+// accumulator registers leave the epilogue no room - every variant tried spilled inside the k-loop.
 template <typename OpT>
 static int dispatch_ln(const GemmParams& p, hipStream_t st) {
-  static const int force = [] { const char* e = getenv("NMTGAN_LN_BM"); return e ? atoi(e) : 0; }();
-  if constexpr (sizeof(OpT) == 2) {
-    if (force == 128) return launch_ln<OpT, 128>(p, st);
-    return launch_ln<OpT, 64>(p, st);
-  }
+  if constexpr (sizeof(OpT) == 2) return launch_ln<OpT, 64>(p, st);
   NMTGAN_FAIL(-2, "gemm: the ADDLN epilogue needs a 16-bit op dtype");
 }
 
@@ -1357,7 +1432,7 @@ static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
   }
   if (a->epilogue == NMTGAN_EPI_ADDLN) {
     NMTGAN_REQUIRE(gemm_addln_supported(a->op_dtype, a->N, a->K),
-                   "gemm: ADDLN needs a 16-bit op dtype, N = 512 and K*esize a multiple of 64 bytes, >= 256 (N=%d K=%d)", a->N, a->K);
+                   "gemm: ADDLN needs a 16-bit op dtype, N = 512 and K*esize a multiple of 128 bytes, >= 256 (N=%d K=%d)", a->N, a->K);
     NMTGAN_REQUIRE(a->a_group <= 0, "gemm: ADDLN takes plain rows (a_group = 0)");
     NMTGAN_REQUIRE(a->ln_x && a->ln_gamma && a->ln_beta, "gemm: ADDLN needs ln_x / ln_gamma / ln_beta");
     NMTGAN_REQUIRE((uintptr_t)a->ln_x % 16 == 0 && (uintptr_t)a->ln_gamma % 16 == 0 && (uintptr_t)a->ln_beta % 16 == 0 &&
