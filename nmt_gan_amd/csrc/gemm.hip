@@ -856,47 +856,72 @@ static int launch_p8(GemmParams p, hipStream_t st) {
 // rows (MT = BM / 16 row blocks x 4 column blocks of 16x16).  The column -> wave -> lane mapping and the order
 // of every sum do not depend on BM or on the tile a row falls in: a row's result is a function of that row alone.
 // k-tiles are 64 BYTES wide (one 16x16x32 MFMA k-step) so that three stages of the 576 / 640-row [A; W] image
-// fit (36 / 40 KiB each).  A DMA instruction writes 16 rows linearly; row r keeps logical 16-byte chunk c at
-// physical chunk c ^ ((r >> 2) & 3): the 16 rows a fragment read touches (r & 3 picks the 64-byte quarter of
-// the 256-byte bank line, (r >> 2) & 3 the swizzle) land on 16 different bank quads.
+// fit.  A DMA instruction writes 16 rows linearly; row r keeps logical 16-byte chunk c at physical chunk
+// c ^ g((r >> 2) & 3) with g = (0, 3, 2, 1).  A ds_read_b128 is served in four groups of 16 lanes that are NOT
+// contiguous - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 - so a group holds rows 0-3 and 12-15 at
+// one k-chunk and rows 4-11 at the next; r & 3 picks the 64-byte quarter of the 256-byte bank line, and g makes the
+// four rows that share a quarter land on four different 16-byte slots in every group.
 // Same stream structure as gemm_pipe_kernel: persistent, loads two k-tiles ahead, counted vmcnt waits.
 constexpr int LBN = 512, LKB = 64, LSCR = 16 * 36 * 4;
 
-template <typename OpT, int BM>
-__global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
-  // a stage holds NI * 8 DMA units of 16 rows; with BM = 64 the last four only pad the count to a multiple of the
-  // 8 waves (they re-fetch W rows into LDS nobody reads), so every wave runs the same counted waits
-  constexpr int MT = BM / 16, ROWS = BM + LBN, NI = (ROWS / 16 + 7) / 8, NUNIT = NI * 8, LSTAGE = NUNIT * 1024;
+template <typename F, int... Hs>
+__device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, Hs...>) {
+  (f(std::integral_constant<int, Hs>{}), ...);
+}
+
+// NW waves side by side: wave w owns columns WC w .. WC w + WC - 1 (WC = 512 / NW) of all BM rows; instantiated as
+// <64, 8> (two waves per SIMD, 64 x 64 wave tiles, 16 MFMAs per wave and k-step).
+template <typename OpT, int BM, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_ln_kernel(GemmParams p) {
+  constexpr int WC = LBN / NW, MT = BM / 16, NT = WC / 16, NJP = NT / 2, ROWS = BM + LBN;
+  // a stage holds NUNIT DMA units of 16 rows (1 KiB each); wave w issues units w, w + NW, ...: NI of them, or NI - 1
+  // when the unit count is not a multiple of the waves (`full` is then false for the last waves)
+  constexpr int NST = 4, NUNIT = ROWS / 16, NI = (NUNIT + NW - 1) / NW, LSTAGE = NUNIT * 1024;
+  constexpr int NA = (BM / 16 + NW - 1) / NW;    // units j < NA of a wave can be A units
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x;
-  const int nkt = p.kbytes / LKB;                // >= 4 (launch guarantees it)
+  const int nkt = p.kbytes / LKB;                // >= 4 and even (launch guarantees it)
   const int my_tiles = (p.ntm - (int)blockIdx.x + G - 1) / G;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
-  constexpr bool full = true;
+  const bool full = (NUNIT % NW == 0) || wave + NW * (NI - 1) < NUNIT;
 
   // DMA sources = uniform base (A tile or W, advanced along k by scalar adds) + a 32-bit per-lane offset: unit
-  // wave + 8 j of the stacked [A; W] image holds rows 16 (wave + 8 j) .. + 15.  Only unit j = 0 can be an A unit
-  // (BM / 16 <= 8); its offsets change with the tile (rows past M re-read row M - 1), the W offsets never do.
-  const bool u0_is_a = wave < BM / 16;
-  const int lc0 = (lane & 3) ^ ((lane >> 4) & 3);                  // (rho >> 2) & 3 == (lane >> 4) & 3: units start at multiples of 16
+  // u = wave + NW j of the stacked [A; W] image holds rows 16 u .. 16 u + 15.  The offsets of A units change with
+  // the tile (rows past M re-read row M - 1), the W offsets never do.
+  // Everything derived from the lane id (DMA offsets, fragment read offsets) is recomputed at the start of every tile
+  // from a value the optimiser cannot see through: the values then do not live across the epilogue, where the
+  // register allocator would spill them and reload them inside the k-loop.
+  int lc0 = 0, a_rd = 0, b_rd = 0, lrow = 0;
   unsigned voff[NI];
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int wrow = 16 * (wave + 8 * j) + (lane >> 2) - BM;       // W row of this lane in unit j (padding units clamp)
-    voff[j] = (unsigned)(min(max(wrow, 0), LBN - 1) * (int)p.ldw_b + lc0 * 16);
-  }
   const char* a_base = p.A;
   auto set_src = [&](int tile) {
-    if (u0_is_a) {
-      const int r = min(tile * BM + 16 * wave + (lane >> 2), p.M - 1) - tile * BM;
-      voff[0] = (unsigned)(r * (int)p.lda_b + lc0 * 16);
-    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if (wave + NW * j < BM / 16) {
+        const int r = min(tile * BM + 16 * (wave + NW * j) + lrow, p.M - 1) - tile * BM;
+        voff[j] = (unsigned)(r * (int)p.lda_b + lc0 * 16);
+      }
     a_base = p.A + (int64_t)tile * BM * p.lda_b;
   };
+  auto lane_state = [&](int tile) {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    lc0 = (l & 3) ^ ((0 - (l >> 4)) & 3);                          // row swizzle g((row >> 2) & 3): units start at multiples of 16 rows
+    lrow = l >> 2;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int wrow = 16 * (wave + NW * j) + lrow - BM;           // W row of this lane in unit j (padding units clamp)
+      voff[j] = (unsigned)(min(max(wrow, 0), LBN - 1) * (int)p.ldw_b + lc0 * 16);
+    }
+    const int pc = ((l >> 4) ^ ((0 - ((l & 15) >> 2)) & 3)) << 4;
+    a_rd = (l & 15) * LKB + pc;
+    b_rd = (BM + wave * WC + (l & 15)) * LKB + pc;
+    set_src(tile);
+  };
   // The (tile, k-step) pairs of the block form ONE stream of `total` k-steps; stage q of the stream lives in LDS buffer
-  // q % 3.  issue_next() sends the DMA of the next stage that has not been requested yet.
+  // q % NST.  issue_next() sends the DMA of the next stage that has not been requested yet.
   const int total = my_tiles * nkt;
   int issued = 0, iss_k = 0, iss_t = 0, is_buf = 0;
   auto issue_next = [&]() {
@@ -909,78 +934,75 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
     const char* ak = a_base + iss_k * LKB;
 #pragma unroll
     for (int j = 0; j < NI; ++j)
-      glds16_s(voff[j], (j == 0 && u0_is_a) ? ak : wk,
-               __builtin_amdgcn_readfirstlane(lds_base + is_buf * LSTAGE + (wave + 8 * j) * 1024));
-    is_buf = is_buf == 2 ? 0 : is_buf + 1;
+      if (j < NI - 1 || full)
+        glds16_s(voff[j], (j < NA && wave + NW * j < BM / 16) ? ak : wk,
+                 __builtin_amdgcn_readfirstlane(lds_base + is_buf * LSTAGE + (wave + NW * j) * 1024));
+    is_buf = (is_buf + 1) & (NST - 1);
     iss_k += 1;
     issued += 1;
   };
 
-  f32x4 acc[MT][4];
+  f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int fc = lane & 15, fq = lane >> 4;
-  const int pc = (fq ^ ((fc >> 2) & 3)) << 4;
-  const int a_rd = fc * LKB + pc;
-  const int b_rd = (BM + wave * 64 + fc) * LKB + pc;
-  float* scr = reinterpret_cast<float*>(smem + 3 * LSTAGE + wave * LSCR);
-  float* stat0 = reinterpret_cast<float*>(smem + 3 * LSTAGE + 8 * LSCR);   // [BM][8] partial row sums per wave
-  float* stat1 = stat0 + BM * 8;
-  float* red0 = stat1 + BM * 8;                    // [BM] row means, [BM] reciprocal deviations
-  float* red1 = red0 + BM;
+  static_assert(NW * LSCR + (2 * BM * NW + 2 * BM) * (int)sizeof(float) <= LSTAGE, "epilogue scratch must fit in one stage buffer");
 
 #define NMTGAN_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-  auto wait_stage = [&]() {                      // all but this wave's newest stage have landed
-    if (full) NMTGAN_WAIT(NI); else NMTGAN_WAIT(NI - 1);
-  };
+  // all but this wave's k newest stages have landed
+#define NMTGAN_WAIT_STAGES(k) do { if (full) NMTGAN_WAIT((k) * NI); else NMTGAN_WAIT((k) * (NI - 1)); } while (0)
   // Fragments are double-buffered in registers: k-step q multiplies the fragments read during k-step q - 1 while the
   // fragments of q + 1 are read from the stage that has just landed, so a wave's LDS reads run under its own MFMAs.
-  // Per k-step: wait (stage q + 1 landed, q + 2 may be in flight) -> this wave's reads of stage q are complete ->
-  // barrier (every wave is past its reads of stage q, whose buffer the DMA of stage q + 3 refills) -> issue q + 3
-  // -> read q + 1 -> 16 MFMAs of q.
-  uint4 fa[2][MT], fb[2][4];
-  auto read_frags = [&](int buf, uint4 (&a)[MT], uint4 (&b)[4]) {
+  // Per k-step: wait (stage q + 1 landed; q + 2 and q + 3 may be in flight) -> this wave's reads of stage q are complete
+  // -> barrier (every wave is past its reads of stage q, whose buffer the DMA of stage q + 4 refills) -> issue q + 4
+  // -> read q + 1 -> the MFMAs of q.  The LAST k-step of a tile issues nothing: the buffer of its own stage stays free
+  // through the epilogue, which uses it as transpose scratch and statistics space; the next k-step issues two stages.
+  uint4 fa[2][MT], fb[2][NT];
+  auto read_frags = [&](int buf, uint4 (&a)[MT], uint4 (&b)[NT]) {
     const unsigned char* base = smem + buf * LSTAGE;
 #pragma unroll
     for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(base + a_rd + i * 16 * LKB);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const uint4*>(base + b_rd + j * 16 * LKB);
+    for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const uint4*>(base + b_rd + j * 16 * LKB);
   };
 
-  // row-major view of a 16 x 32 piece in the epilogue: row rl + 8 t, columns c4 .. c4 + 3 (rl = lane >> 3, c4 = 4 * (lane & 7))
-  const int ncol = 64 * wave;
+  const int ncol = WC * wave;
   int rbuf = 0;                                    // LDS buffer of the next stage whose fragments have not been read
-  auto epilogue_ln = [&](int t) {
+  auto epilogue_ln = [&](int t, int free_buf) {
+    float* scr = reinterpret_cast<float*>(smem + free_buf * LSTAGE + wave * LSCR);
+    float* stat0 = reinterpret_cast<float*>(smem + free_buf * LSTAGE + NW * LSCR);   // [BM][NW] partial row sums per wave
+    float* stat1 = stat0 + BM * NW;
+    float* red0 = stat1 + BM * NW;                 // [BM] row means, [BM] reciprocal deviations
+    float* red1 = red0 + BM;
     // lane-derived indices are recomputed here from a value the optimiser cannot see through: otherwise it hoists the
     // ~50 loop-invariant offsets of the epilogue out of the k-step loop and spills them
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int fc = lane_e & 15, fq = lane_e >> 4, c4 = 4 * (lane_e & 7), rl = lane_e >> 3;
-    // ---- epilogue.  The accumulators stay where the MFMAs left them (16x16 C layout: column = lane & 15, row =
-    // 4 * (lane >> 4) + e) from the residual add to the normalised value; only the global loads and stores use the
-    // row-major view (16 bytes per lane, whole 128-byte row segments per instruction), and each 16 x 32 piece
-    // changes view through the wave's LDS scratch.  Register peak: the accumulators plus one set of residual loads.
+    // The accumulators stay where the MFMAs left them (16x16 C layout: column = lane & 15, row = 4 * (lane >> 4) + e)
+    // from the residual add to the normalised value; only the global loads and stores use the row-major view of a
+    // 16 x 32 piece (row rl + 8 t, columns c4 .. c4 + 3: 16 bytes per lane, whole 128-byte row segments per
+    // instruction), and each piece changes view through the wave's LDS scratch.
     // addresses = one uniform tile base + a 32-bit lane offset (a 64-bit address per access would cost two registers each)
     const int m0 = ((int)blockIdx.x + t * G) * BM;
     const int rows_here = min(BM, p.M - m0);
     float* xt = p.ln_x + (int64_t)m0 * LBN;
     OpT* ot = p.ln_out ? reinterpret_cast<OpT*>(p.ln_out) + (int64_t)m0 * LBN : nullptr;
     const int col = ncol + c4;
-    float bias[4];
+    float bias[NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bias[j] = p.bias ? p.bias[ncol + 16 * j + fc] : 0.f;
-    // the residual loads of the tile's 64 rows go out together, then each 16 x 32 piece changes view
-    constexpr int GI = 4;
+    for (int j = 0; j < NT; ++j) bias[j] = p.bias ? p.bias[ncol + 16 * j + fc] : 0.f;
+    // GI row blocks at a time (16 residual loads of 16 bytes per lane in flight), then each 16 x 32 piece changes view
+    constexpr int GI = 8 / NJP;
     auto add_residual = [&](auto H) {
       constexpr int h = decltype(H)::value;
-      f32x4 res[GI][2][2];
+      f32x4 res[GI][NJP][2];
 #pragma unroll
       for (int i = 0; i < GI; ++i)
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp)
+        for (int jp = 0; jp < NJP; ++jp)
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) {           // rows past M re-read the last row: no predicate, no branch
             const unsigned off = (unsigned)(min(16 * (GI * h + i) + rl + 8 * tt, rows_here - 1) * LBN + col + 32 * jp);
@@ -989,7 +1011,7 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < GI; ++i)
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
+        for (int jp = 0; jp < NJP; ++jp) {
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) *reinterpret_cast<f32x4*>(scr + (rl + 8 * tt) * 36 + c4) = res[i][jp][tt];
 #pragma unroll
@@ -1001,46 +1023,57 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
           __builtin_amdgcn_sched_barrier(0);       // piece by piece: the scheduler otherwise gathers every piece's
         }                                          // LDS reads in front of the adds and spills them
     };
-    add_residual(std::integral_constant<int, 0>{});
-    static_assert(MT == 4, "one residual group per tile");
-    // sum over a row: the lane's 4 columns, the 16 lanes of the row's group, then the 8 waves in wave order by ONE
+    for_each_const(add_residual, std::make_integer_sequence<int, MT / GI>{});
+    // sum over a row: the lane's NT columns, the 16 lanes of the row's group, then the NW waves in wave order by ONE
     // thread per row, which leaves the row's mean / reciprocal deviation in red[row] for every wave to pick up
     auto row_total = [&](float s, float* stat, int row) {
       s = dpp_add<0xB1>(s);
       s = dpp_add<0x4E>(s);
       s = dpp_add<0x141>(s);
       s = dpp_add<0x140>(s);
-      if (fc == 0) stat[row * 8 + wave] = s;
+      if (fc == 0) stat[row * NW + wave] = s;
     };
-    auto row_sum8 = [&](const float* stat, int row) {
-      const float4 a = *reinterpret_cast<const float4*>(stat + row * 8);
-      const float4 b = *reinterpret_cast<const float4*>(stat + row * 8 + 4);
-      return ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+    auto row_sum = [&](const float* stat, int row) {
+      const float4 a = *reinterpret_cast<const float4*>(stat + row * NW);
+      float s = (a.x + a.y) + (a.z + a.w);
+      if constexpr (NW == 8) {
+        const float4 b = *reinterpret_cast<const float4*>(stat + row * NW + 4);
+        s += (b.x + b.y) + (b.z + b.w);
+      }
+      return s;
+    };
+    auto lane_sum = [&](const float (&v)[NT]) {
+      float s = (v[0] + v[1]) + (v[2] + v[3]);
+      if constexpr (NT == 8) s += (v[4] + v[5]) + (v[6] + v[7]);
+      return s;
     };
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        row_total((acc[i][0][e] + acc[i][1][e]) + (acc[i][2][e] + acc[i][3][e]), stat0, 16 * i + 4 * fq + e);
+        float v[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j] = acc[i][j][e];
+        row_total(lane_sum(v), stat0, 16 * i + 4 * fq + e);
       }
     __syncthreads();
-    if (tid < BM) red0[tid] = row_sum8(stat0, tid) * (1.0f / LBN);
+    if (tid < BM) red0[tid] = row_sum(stat0, tid) * (1.0f / LBN);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float mean = red0[16 * i + 4 * fq + e];
-        float q = 0.f;
+        float v[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NT; ++j) {
           acc[i][j][e] -= mean;
-          q += acc[i][j][e] * acc[i][j][e];
+          v[j] = acc[i][j][e] * acc[i][j][e];
         }
-        row_total(q, stat1, 16 * i + 4 * fq + e);
+        row_total(lane_sum(v), stat1, 16 * i + 4 * fq + e);
       }
     __syncthreads();
-    if (tid < BM) red1[tid] = rsqrtf(row_sum8(stat1, tid) * (1.0f / LBN) + 1e-6f);
+    if (tid < BM) red1[tid] = rsqrtf(row_sum(stat1, tid) * (1.0f / LBN) + 1e-6f);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -1048,18 +1081,18 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
       for (int e = 0; e < 4; ++e) {
         const float rs = red1[16 * i + 4 * fq + e];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j][e] *= rs;
+        for (int j = 0; j < NT; ++j) acc[i][j][e] *= rs;
       }
-    f32x4 gam[2], bet[2];
+    f32x4 gam[NJP], bet[NJP];
 #pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
+    for (int jp = 0; jp < NJP; ++jp) {
       gam[jp] = *reinterpret_cast<const f32x4*>(p.ln_gamma + ncol + 32 * jp + c4);
       bet[jp] = *reinterpret_cast<const f32x4*>(p.ln_beta + ncol + 32 * jp + c4);
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
+      for (int jp = 0; jp < NJP; ++jp) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -1081,41 +1114,46 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  auto kstep = [&](int q, const uint4 (&ca)[MT], const uint4 (&cb)[4], uint4 (&na)[MT], uint4 (&nb)[4], bool read_next) {
+  auto kstep = [&](int q, const uint4 (&ca)[MT], const uint4 (&cb)[NT], uint4 (&na)[MT], uint4 (&nb)[NT], bool last) {
     if (q + 1 < total) {
-      if (q + 2 < issued) wait_stage(); else NMTGAN_WAIT(0);
+      const int ahead = issued - (q + 2);          // stages requested beyond q + 1
+      if (ahead >= 2) NMTGAN_WAIT_STAGES(2);
+      else if (ahead == 1) NMTGAN_WAIT_STAGES(1);
+      else NMTGAN_WAIT(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (issued < total) issue_next();
-    if (read_next) {
+    if (!last) {
+      if (issued < total && issued < q + 1 + NST) issue_next();
+      if (issued < total && issued < q + 1 + NST) issue_next();    // catches up after a tile's last k-step
       read_frags(rbuf, na, nb);
-      rbuf = rbuf == 2 ? 0 : rbuf + 1;
+      rbuf = (rbuf + 1) & (NST - 1);
     }
-    mma_block<OpT, MT, 4, 0, 0>(ca, cb, acc);
+    mma_block<OpT, MT, NT, 0, 0>(ca, cb, acc);
   };
-  set_src((int)blockIdx.x);
-  issue_next();
-  issue_next();
-  issue_next();
-  NMTGAN_WAIT(2 * NI);
+  lane_state((int)blockIdx.x);
+#pragma unroll
+  for (int i = 0; i < NST; ++i) issue_next();    // total >= nkt >= 4
+  NMTGAN_WAIT_STAGES(NST - 1);
   __builtin_amdgcn_s_barrier();
   int q = 0;
   for (int t = 0; t < my_tiles; ++t) {
+    lane_state((int)blockIdx.x + iss_t * G);     // unconditional: the old values are dead here (the DMA stream is 0 or 1 tiles ahead)
     // the tile's first fragments are read here and not under the previous tile's last MFMAs: nothing but the
     // accumulators stays live across the epilogue
     read_frags(rbuf, fa[0], fb[0]);
-    rbuf = rbuf == 2 ? 0 : rbuf + 1;
+    rbuf = (rbuf + 1) & (NST - 1);
 #pragma unroll 1
-    for (int kp = 0; kp < nkt / 2; ++kp) {         // nkt is even (launch guarantees it)
-      kstep(q, fa[0], fb[0], fa[1], fb[1], true);
-      kstep(q + 1, fa[1], fb[1], fa[0], fb[0], kp + 1 < nkt / 2);
+    for (int kp = 0; kp < nkt / 2; ++kp) {
+      kstep(q, fa[0], fb[0], fa[1], fb[1], false);
+      kstep(q + 1, fa[1], fb[1], fa[0], fb[0], kp + 1 == nkt / 2);
       q += 2;
     }
-    epilogue_ln(t);
+    epilogue_ln(t, (q - 1) & (NST - 1));
   }
+#undef NMTGAN_WAIT_STAGES
 #undef NMTGAN_WAIT
 }
 
@@ -1250,29 +1288,31 @@ static int launch_generic(GemmParams p, hipStream_t st) {
   return 0;
 }
 
-template <typename OpT, int BM>
+template <typename OpT, int BM, int NW>
 static int launch_ln(GemmParams p, hipStream_t st) {
-  // three stages (each padded to a multiple of 8 DMA units of 1 KiB), per-wave scratch, two [BM][8] + two [BM] statistics arrays
-  constexpr int smem = 3 * (((BM + LBN) / 16 + 7) / 8 * 8) * 1024 + 8 * LSCR + (2 * BM * 8 + 2 * BM) * (int)sizeof(float);
+  // four stages of (BM + 512) rows x 64 bytes; the epilogue's scratch and statistics live in the stage buffer it keeps free
+  constexpr int smem = 4 * (BM + LBN) * LKB;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_kernel<OpT, BM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_kernel<OpT, BM, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       NMTGAN_FAIL(-3, "gemm: cannot raise dynamic LDS limit");
     attr_done = true;
   }
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = 1;
-  hipLaunchKernelGGL((gemm_ln_kernel<OpT, BM>), dim3(persistent_grid(p.ntm)), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((gemm_ln_kernel<OpT, BM, NW>), dim3(persistent_grid(p.ntm)), dim3(64 * NW), smem, st, p);
   NMTGAN_CHECK_LAUNCH("gemm_ln");
   return 0;
 }
-// 64-row tiles only: a 128-row tile would halve the L2 -> LDS traffic per flop (the 512 W rows are re-fetched per
-// tile: 34 KB per MMAC against 16-23 for the plain kernels, which is what bounds this kernel at K = 2048), but its 128
-// accumulator registers leave the epilogue no room - every variant tried spilled inside the k-loop.
+// Eight waves on 64-row tiles.  Measured alternatives (fp16, M = 49152): the same kernel as <128, 4> - four waves, one
+// per SIMD, 128 x 128 wave tiles, half the W re-fetch per flop - runs K = 512 / 2048 in 135 / 254 us against 83 / 196:
+// with 32 KiB of W per 64-byte k-step only three stages fit in LDS, and two stages in flight per CU do not cover the
+// L2 -> LDS latency (a lone tile takes 44 us at K = 512); <128, 8> spills inside the k-loop.  K = 2048 therefore stays
+// on the 256x256 kernel + add_layernorm (176 us).
 template <typename OpT>
 static int dispatch_ln(const GemmParams& p, hipStream_t st) {
-  if constexpr (sizeof(OpT) == 2) return launch_ln<OpT, 64>(p, st);
+  if constexpr (sizeof(OpT) == 2) return launch_ln<OpT, 64, 8>(p, st);
   NMTGAN_FAIL(-2, "gemm: the ADDLN epilogue needs a 16-bit op dtype");
 }
 
