@@ -29,12 +29,13 @@ y, mask = N.deal_generated_samples(y)
 xp = N.extend_sentence_to_maxlen(x, T)
 u = model.make_uniforms(R, T, B, seed=2024)
 
-whole = model.prepare_reward(x, xp, y, mask, R, disc, T, 0.6, u)
+MODE = os.environ.get("SPLIT_MODE", "both")          # whole | parts | both: a HIP stream keeps the hardware queue it was
+whole = model.prepare_reward(x, xp, y, mask, R, disc, T, 0.6, u) if MODE != "parts" else None   # created on (4 per process)
 bounds = split_bounds(B, K)
 parts = []
 for i in range(K):
     b0, b1 = bounds[i], bounds[i + 1]
-    st = torch.cuda.Stream(device=dev)
+    st = None if i == 0 else torch.cuda.Stream(device=dev)     # the first sub-batch on the default stream (its own queue)
     parts.append(model.prepare_reward(x[b0:b1], xp[b0:b1], y[b0:b1], mask[b0:b1], R, disc, T, 0.6, u, b_offset=b0, B_global=B,
                                       own_workspace=True, stream=st))
 
@@ -57,9 +58,14 @@ def timed(fn, n=3):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-t_whole = timed(run_whole)
-ref = whole.tensors["rewards"].clone()
-t_parts = timed(run_parts)
-got = torch.cat([p.tensors["rewards"] for p in parts])
-print("B=%d: whole %.1f ms, %d sub-batches on their own streams %.1f ms; identical rewards: %s"
-      % (B, t_whole, K, t_parts, bool(torch.equal(ref, got))), flush=True)
+if MODE == "parts":
+    print("B=%d: %d sub-batches on their own streams %.1f ms" % (B, K, timed(run_parts)), flush=True)
+elif MODE == "whole":
+    print("B=%d: whole %.1f ms" % (B, timed(run_whole)), flush=True)
+else:
+    t_whole = timed(run_whole)
+    ref = whole.tensors["rewards"].clone()
+    t_parts = timed(run_parts)
+    got = torch.cat([p.tensors["rewards"] for p in parts])
+    print("B=%d: whole %.1f ms, %d sub-batches on their own streams %.1f ms; identical rewards: %s"
+          % (B, t_whole, K, t_parts, bool(torch.equal(ref, got))), flush=True)
