@@ -93,7 +93,7 @@ PROFILE_TAG = {"fp16": "r2_c2_fp16", "bf16": "r1_c2_bf16"}     # committed PMC s
 # type prints as `unsigned short` for bf16 and `_Float16` for fp16)
 TRAFFIC_KERNELS = {
     "gemm_conv": r"gemm_\w+_kernel<(unsigned short|_Float16), 1[,>]",
-    "gemm_logits": r"gemm_\w+_kernel<(unsigned short|_Float16), (2|100)[,>]",     # 2 in the round-1 summary
+    "gemm_logits": r"gemm_\w+_kernel<(unsigned short|_Float16), (2|100)[,>]",     # 2 in the bf16 summary, made by an earlier build
     "attn_self_private": r"attn_rows_(bf16|16)_kernel",
     "add_layernorm": r"addln_kernel",
     "sampler_rows": r"sample_kernel",
