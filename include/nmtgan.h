@@ -135,6 +135,15 @@ typedef struct {
 int nmtgan_add_layernorm(const nmtgan_addln_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Split-precision GEMM operand: A [M][K] fp32 (row stride lda) -> out [M][3K] fp16 = [A_hi | A_lo | A_hi] with
+ * A_hi = fp16(A), A_lo = fp16(A - A_hi).  Against weights packed [N][3K] = [W_hi | W_hi | W_lo] one fp16 nmtgan_gemm over
+ * 3K computes A_hi.W_hi + A_lo.W_hi + A_hi.W_lo: tf.matmul / conv2d 1x1 in fp32 (same call sites as nmtgan_gemm) to about
+ * 21 significand bits per operand at the fp16 matrix-core rate.  What the generator pipelines do per GEMM when
+ * nmtgan_generator.gemm_split is set.  K % 8 == 0, lda % 4 == 0, 16-byte aligned pointers.
+ */
+int nmtgan_split3(const float* A, int64_t lda, int M, int K, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Row attention: one query row against (1) a block of shared keys and (2) its private suffix.
  * Replaces dot_product_attention (common_attention.py:294-331) for: encoder self-attention
  * (padding mask), decoder causal self-attention (prefill and the incremental rollout step),
@@ -256,6 +265,13 @@ typedef struct {                       /* Model weights (model.py:486-618, 772-8
   const float* timing; int max_pos;    /* [max_pos][d] fp32 */
   nmtgan_enc_block enc[NMTGAN_MAX_BLOCKS];
   nmtgan_dec_block dec[NMTGAN_MAX_BLOCKS];
+  int gemm_split;                      /* != 0 (needs op_dtype NMTGAN_F32): every dense layer and the softmax table are
+                                          packed as fp16 [N][3K] = [W_hi | W_hi | W_lo] (W_hi = fp16(W), W_lo = fp16(W - W_hi));
+                                          the pipelines split each fp32 GEMM input the same way on the fly,
+                                          [A_hi | A_lo | A_hi], and run the product as ONE fp16 MFMA GEMM over 3K:
+                                          A_hi.W_hi + A_lo.W_hi + A_hi.W_lo, about 21 significand bits per operand at
+                                          three times the fp16 cost instead of the fp32 matrix-core rate.  Activations,
+                                          K/V caches, attention and LayerNorm stay fp32 as in the fp32 tier. */
 } nmtgan_generator;
 
 typedef struct {                       /* one tower of DisCNN (cnn_discriminator.py:454-482) */

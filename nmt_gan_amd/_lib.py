@@ -81,7 +81,7 @@ class Generator(C.Structure):
     _fields_ = [("op_dtype", i32), ("d", i32), ("heads", i32), ("n_blocks", i32), ("vocab_src", i32),
                 ("vocab_dst", i32), ("emb_mult", f32), ("emb_src", vp), ("emb_dst", vp), ("softmax_w", vp),
                 ("timing", vp), ("max_pos", i32),
-                ("enc", EncBlock * MAX_BLOCKS), ("dec", DecBlock * MAX_BLOCKS)]
+                ("enc", EncBlock * MAX_BLOCKS), ("dec", DecBlock * MAX_BLOCKS), ("gemm_split", i32)]
 
 
 class DiscTower(C.Structure):
@@ -122,6 +122,7 @@ EXPORTS = {
     "nmtgan_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "nmtgan_embed": (i32, [C.POINTER(EmbedArgs), vp]),
     "nmtgan_add_layernorm": (i32, [C.POINTER(AddLnArgs), vp]),
+    "nmtgan_split3": (i32, [vp, i64, i32, i32, vp, vp]),
     "nmtgan_attn_rows": (i32, [C.POINTER(AttnArgs), vp]),
     "nmtgan_sample_rows": (i32, [C.POINTER(SampleArgs), vp]),
     "nmtgan_logits_sample_workspace_bytes": (sz, [i32, i32]),
@@ -190,6 +191,19 @@ def op_dtype_of(precision: str):
     if precision not in table:
         raise ValueError("precision must be 'fp16', 'bf16' or 'fp32'")
     return table[precision]
+
+
+SPLIT_PRECISION = "fp16x3"       # generator tier: fp32 storage, every GEMM as one fp16 MFMA product over [hi | lo] splits
+
+
+def split3_weights(w):
+    """fp32 [N, K] (torch, any device) -> fp16 [N, 3K] = [W_hi | W_hi | W_lo], W_hi = fp16(W), W_lo = fp16(W - W_hi):
+    the weight side of nmtgan_generator.gemm_split (the activation side is [A_hi | A_lo | A_hi])."""
+    import torch
+    w = w.to(torch.float32)
+    hi = w.to(torch.float16)
+    lo = (w - hi.to(torch.float32)).to(torch.float16)
+    return torch.cat([hi, hi, lo], dim=1).contiguous()
 
 
 def check(rc: int, what: str = "nmtgan"):

@@ -55,6 +55,8 @@ class DisCNN(object):
         self.num_filters_total = int(sum(self.num_filters))
         self.scope = scope
         self.saveto = saveto
+        if precision == _lib.SPLIT_PRECISION:      # the generator's split-precision tier pairs with an fp16 discriminator
+            precision = "fp16"
         self.precision = precision
         self.device = torch.device(device)
         self.chunk_rows = int(chunk_rows)

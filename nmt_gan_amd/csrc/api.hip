@@ -97,6 +97,9 @@ int nmtgan_embed(const nmtgan_embed_args* a, void* stream) { return launch_embed
 int nmtgan_add_layernorm(const nmtgan_addln_args* a, void* stream) {
   return launch_add_layernorm(a, (hipStream_t)stream);
 }
+int nmtgan_split3(const float* A, int64_t lda, int M, int K, void* out, void* stream) {
+  return launch_split3(A, lda, M, K, out, (hipStream_t)stream);
+}
 int nmtgan_attn_rows(const nmtgan_attn_args* a, void* stream) { return launch_attn_rows(a, (hipStream_t)stream); }
 int nmtgan_attn_group(const nmtgan_attn_group_args* a, void* stream) {
   return launch_attn_group(a, (hipStream_t)stream);

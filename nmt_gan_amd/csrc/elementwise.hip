@@ -122,6 +122,42 @@ int launch_add_layernorm(const nmtgan_addln_args* a, hipStream_t st) {
   return 0;
 }
 
+// ------------------------------------------------------------------ split-precision GEMM operand
+__global__ __launch_bounds__(256) void split3_kernel(const float* A, int64_t lda, int M, int K, f16_t* out) {
+  const int kc = K / 8;                            // 8-element chunks per row
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * kc) return;
+  const int64_t m = i / kc;
+  const int c = (int)(i % kc);
+  float v[8];
+  VecIO<float, 8>::load(A + m * lda + 8 * c, v);
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f16_t h0 = (f16_t)v[2 * e], h1 = (f16_t)v[2 * e + 1];
+    const f16x2_t h = {h0, h1};
+    const f16x2_t l = {(f16_t)(v[2 * e] - (float)h0), (f16_t)(v[2 * e + 1] - (float)h1)};
+    hi[e] = __builtin_bit_cast(unsigned, h);
+    lo[e] = __builtin_bit_cast(unsigned, l);
+  }
+  f16_t* o = out + m * 3 * K + 8 * c;
+  const uint4 h4 = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  *reinterpret_cast<uint4*>(o) = h4;
+  *reinterpret_cast<uint4*>(o + K) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  *reinterpret_cast<uint4*>(o + 2 * K) = h4;
+}
+
+int launch_split3(const float* A, int64_t lda, int M, int K, void* out, hipStream_t st) {
+  prof::Scope prof_scope(prof::OTHER, st);
+  if (M == 0) return 0;
+  NMTGAN_REQUIRE(A && out && M > 0 && K > 0 && K % 8 == 0 && lda % 4 == 0, "split3: bad arguments (K %% 8, lda %% 4)");
+  NMTGAN_REQUIRE((uintptr_t)A % 16 == 0 && (uintptr_t)out % 16 == 0, "split3: operands must be 16-byte aligned");
+  const int64_t n = (int64_t)M * (K / 8);
+  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, lda, M, K, (f16_t*)out);
+  NMTGAN_CHECK_LAUNCH("split3");
+  return 0;
+}
+
 // ------------------------------------------------------------------ rollout tokens
 // Y[row][t] = y[b][t] for t < g else 0 (model.py:250-252: given_y = Y[:, :given_num], zero padded)
 __global__ void init_rollouts_kernel(const int32_t* y, const int32_t* row_b, const int32_t* row_g, int n_rows, int T,

@@ -22,6 +22,9 @@ struct SplitKScope {
   SplitKScope(void* buf, size_t bytes) { set_gemm_splitk_scratch(buf, bytes); }
   ~SplitKScope() { set_gemm_splitk_scratch(nullptr, 0); }
 };
+// [M][K] fp32 (row stride lda) -> [M][3K] fp16 = [hi | lo | hi], hi = fp16(a), lo = fp16(a - hi): the A operand of the
+// split-precision GEMM form (nmtgan_generator.gemm_split); K % 8 == 0, 16-byte aligned rows
+int launch_split3(const float* A, int64_t lda, int M, int K, void* out, hipStream_t st);
 int launch_logits_sample(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
                          const int64_t* u_off, int64_t u_add, int32_t* out, void* ws, hipStream_t st);
 size_t logits_sample_workspace(int M, int V);

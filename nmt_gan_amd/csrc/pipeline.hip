@@ -16,6 +16,24 @@ namespace nmtgan {
 
 static inline char* at(const void* base, int64_t elems, int es) { return (char*)base + elems * es; }
 
+// Split-precision GEMM form of the calling thread (nmtgan_generator.gemm_split): scratch for the split A operand.
+// Set by the generator pipelines around their launches; everything they enqueue goes to ONE stream, in order, so one
+// buffer serves every GEMM.
+static thread_local void* g_split_buf = nullptr;
+static thread_local size_t g_split_bytes = 0;
+struct SplitScope {
+  SplitScope(const nmtgan_generator* g, void* buf, size_t bytes) {
+    g_split_buf = g->gemm_split ? buf : nullptr;
+    g_split_bytes = g->gemm_split ? bytes : 0;
+  }
+  ~SplitScope() { g_split_buf = nullptr; g_split_bytes = 0; }
+};
+// A [M][K] fp32 -> the thread's scratch as fp16 [M][3K] = [hi | lo | hi]
+static int split_operand(const void* A, int64_t lda, int M, int K, hipStream_t st) {
+  NMTGAN_REQUIRE((size_t)M * 3 * K * sizeof(f16_t) <= g_split_bytes, "split GEMM: scratch too small for %d x %d", M, K);
+  return launch_split3((const float*)A, lda, M, K, g_split_buf, st);
+}
+
 // out[s] = (A . Wt^T + b) with up to 3 column segments
 static int dense(int op, const void* A, int64_t lda, int M, int K, int N, const nmtgan_dense& w, int n_seg,
                  int seg_width, void* const* outs, const int64_t* ldos, const int* out_f32, const float* scales,
@@ -26,6 +44,11 @@ static int dense(int op, const void* A, int64_t lda, int M, int K, int N, const 
   a.bias = w.b; a.relu = relu; a.n_seg = n_seg; a.seg_width = seg_width;
   for (int s = 0; s < n_seg; ++s) {
     a.out[s] = outs[s]; a.ldo[s] = ldos[s]; a.out_f32[s] = out_f32[s]; a.seg_scale[s] = scales ? scales[s] : 1.f;
+  }
+  if (g_split_buf && op == NMTGAN_F32) {           // w.w is fp16 [N][3K] = [hi | hi | lo]; outputs stay fp32
+    NMTGAN_TRY(split_operand(A, lda, M, K, st));
+    a.op_dtype = NMTGAN_F16; a.A = g_split_buf; a.lda = 3 * (int64_t)K; a.K = 3 * K;
+    for (int s = 0; s < n_seg; ++s) a.out_f32[s] = 1;
   }
   return launch_gemm(&a, st);
 }
@@ -75,20 +98,24 @@ static int check_generator(const nmtgan_generator* g) {
   NMTGAN_REQUIRE(g->n_blocks > 0 && g->n_blocks <= NMTGAN_MAX_BLOCKS, "generator: bad num_blocks");
   NMTGAN_REQUIRE(g->vocab_dst % 4 == 0, "generator: dst_vocab_size must be a multiple of 4 (pad the softmax table)");
   NMTGAN_REQUIRE(g->emb_src && g->emb_dst && g->softmax_w && g->timing, "generator: null table");
+  NMTGAN_REQUIRE(!g->gemm_split || g->op_dtype == NMTGAN_F32, "generator: gemm_split needs op_dtype NMTGAN_F32");
   return 0;
 }
 
 // ------------------------------------------------------------------------------------------ activations
 struct Act {
   float* xf; void* xo; float* yf; float* q; void* ao; void* h;
+  void* split; size_t split_bytes;            // split A operand of the widest GEMM (K = 4 d): rows x 12 d fp16
 };
-static void carve_act(Arena& ar, int64_t rows, int d, int es, Act& a) {
+static void carve_act(Arena& ar, int64_t rows, int d, int es, Act& a, bool gemm_split = false) {
   a.xf = ar.get<float>(rows * d);
   a.xo = ar.take(rows * d * es);
   a.yf = ar.get<float>(rows * d);
   a.q = ar.get<float>(rows * d);
   a.ao = ar.take(rows * d * es);
   a.h = ar.take(rows * 4 * d * es);
+  a.split_bytes = gemm_split ? (size_t)rows * 12 * d * sizeof(f16_t) : 0;
+  a.split = gemm_split ? ar.take(a.split_bytes) : nullptr;
 }
 
 // ------------------------------------------------------------------------------------------ encoder
@@ -520,7 +547,7 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   int64_t act_rows = enc_rows > pre_rows ? enc_rows : pre_rows;
   if (p->n_steps >= 1 && p->live[1] > act_rows) act_rows = p->live[1];
   b.act_rows = act_rows;
-  carve_act(ar, act_rows, dm, es, b.act);
+  carve_act(ar, act_rows, dm, es, b.act, g->gemm_split != 0);
   b.kbuf = ar.take(enc_rows * dm * es);
   b.vbuf = ar.take(enc_rows * dm * es);
   b.crossK = ar.take(N * enc_rows * dm * es);
@@ -549,7 +576,8 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   if (p->n_steps >= 1 && p->live[1] < lrows) lrows = p->live[1];
   if (lrows < 1) lrows = 1;
   static const bool fused_env = [] { const char* e = getenv("NMTGAN_FUSED_SAMPLE"); return !e || atoi(e) != 0; }();
-  b.fused = fused_env && p->n_steps >= 1 && gemm_stats_supported(g->op_dtype, g->vocab_dst, dm);
+  b.fused = fused_env && p->n_steps >= 1 &&
+            (g->gemm_split ? gemm_stats_supported(NMTGAN_F16, g->vocab_dst, 3 * dm) : gemm_stats_supported(g->op_dtype, g->vocab_dst, dm));
   b.fused_ws = b.fused ? ar.take(logits_sample_workspace(p->live[1], g->vocab_dst)) : nullptr;
   if (b.fused) lrows = 1;
   b.logits_rows = lrows;
@@ -600,7 +628,10 @@ static int check_plan(const nmtgan_generator* g, const nmtgan_discriminator* d, 
   NMTGAN_TRY(check_generator(g));
   NMTGAN_TRY(check_disc(d));
   NMTGAN_REQUIRE(p != nullptr, "plan: null");
-  NMTGAN_REQUIRE(g->op_dtype == d->op_dtype, "generator and discriminator must be packed in the same op dtype");
+  // the two networks share no activation buffer; the split-precision generator (fp32 storage) pairs with a 16-bit
+  // discriminator, every other tier packs both alike
+  NMTGAN_REQUIRE(g->op_dtype == d->op_dtype || g->gemm_split,
+                 "generator and discriminator must be packed in the same op dtype");
   NMTGAN_REQUIRE(p->B > 0 && p->Ls > 0 && p->T > 1 && p->rollnum > 0, "plan: bad B/Ls/T/rollnum");
   NMTGAN_REQUIRE(p->T == d->max_len, "plan: max_len %d != discriminator max_len %d", p->T, d->max_len);
   NMTGAN_REQUIRE(p->Ls <= g->max_pos && p->T <= g->max_pos, "plan: length exceeds timing table");
@@ -641,6 +672,7 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
   NMTGAN_TRY(carve_reward(ar, g, d, p, b));
   NMTGAN_REQUIRE(ws != nullptr && !ar.overflow, "rollout_reward: workspace too small (%zu < %zu)", ws_bytes, ar.off);
   const int B = p->B, Ls = p->Ls, T = p->T, dm = g->d, V = g->vocab_dst, op = g->op_dtype;
+  SplitScope split_gemm(g, b.act.split, b.act.split_bytes);
 
   // 1. encoder once, cross K/V once per block (the reference re-encodes on every sess.run)
   NMTGAN_TRY(encode(g, p->x, p->x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
@@ -765,7 +797,11 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
         c.slot_table = p->grp_table; c.slots = p->grp_slots; c.n_entries = p->grp_live[step];
       }
       NMTGAN_TRY(decoder_pass(g, M, b.act, c, st));
-      if (b.fused) {
+      if (b.fused && g->gemm_split) {    // the split operands through the fp16 form of the fused path: K = 3 d
+        NMTGAN_TRY(split_operand(b.act.xo, dm, M, dm, st));
+        NMTGAN_TRY(launch_logits_sample(NMTGAN_F16, g_split_buf, g->softmax_w, M, V, 3 * dm, p->uniforms, p->row_uoff, step,
+                                        b.tok_cur, b.fused_ws, st));
+      } else if (b.fused) {
         NMTGAN_TRY(launch_logits_sample(op, b.act.xo, g->softmax_w, M, V, dm, p->uniforms, p->row_uoff, step, b.tok_cur,
                                         b.fused_ws, st));
       } else for (int r0 = 0; r0 < M; r0 += (int)b.logits_rows) {
@@ -797,7 +833,7 @@ struct TfBufs { Act act; void *kbuf, *vbuf, *crossK, *crossV, *shK, *shV; };
 static void carve_tf(Arena& ar, const nmtgan_generator* g, int B, int Ls, int T, TfBufs& b) {
   const int es = dtype_size(g->op_dtype), dm = g->d, N = g->n_blocks;
   const int64_t enc_rows = (int64_t)B * Ls, pre_rows = (int64_t)B * T;
-  carve_act(ar, enc_rows > pre_rows ? enc_rows : pre_rows, dm, es, b.act);
+  carve_act(ar, enc_rows > pre_rows ? enc_rows : pre_rows, dm, es, b.act, g->gemm_split != 0);
   b.kbuf = ar.take(enc_rows * dm * es);
   b.vbuf = ar.take(enc_rows * dm * es);
   b.crossK = ar.take(N * enc_rows * dm * es);
@@ -822,6 +858,7 @@ int teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, const uin
   TfBufs b;
   carve_tf(ar, g, B, Ls, T, b);
   NMTGAN_REQUIRE(ws != nullptr && !ar.overflow, "teacher_forced: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+  SplitScope split_gemm(g, b.act.split, b.act.split_bytes);
   NMTGAN_TRY(encode(g, x, x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
   NMTGAN_TRY(cross_kv(g, b.act.xo, B * Ls, b.crossK, b.crossV, st));
   NMTGAN_TRY(prefill(g, dec_in, x_pad, B, Ls, T, b.act, b.shK, b.shV, b.crossK, b.crossV, st));
@@ -843,7 +880,7 @@ struct GreedyBufs {
 static void carve_greedy(Arena& ar, const nmtgan_generator* g, int B, int Ls, int T, GreedyBufs& b) {
   const int es = dtype_size(g->op_dtype), dm = g->d, N = g->n_blocks;
   const int64_t enc_rows = (int64_t)B * Ls;
-  carve_act(ar, enc_rows > B ? enc_rows : B, dm, es, b.act);
+  carve_act(ar, enc_rows > B ? enc_rows : B, dm, es, b.act, g->gemm_split != 0);
   b.kbuf = ar.take(enc_rows * dm * es);
   b.vbuf = ar.take(enc_rows * dm * es);
   b.crossK = ar.take(N * enc_rows * dm * es);
@@ -879,6 +916,7 @@ int generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* 
   carve_greedy(ar, g, B, Ls, T, b);
   NMTGAN_REQUIRE(ws != nullptr && !ar.overflow, "generate: workspace too small (%zu < %zu)", ws_bytes, ar.off);
   const int dm = g->d, V = g->vocab_dst, op = g->op_dtype;
+  SplitScope split_gemm(g, b.act.split, b.act.split_bytes);
   NMTGAN_TRY(encode(g, x, x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
   NMTGAN_TRY(cross_kv(g, b.act.xo, B * Ls, b.crossK, b.crossV, st));
   const int nfill = T > B ? T : B;

@@ -73,7 +73,9 @@ class Model(object):
         self._logger = logging.getLogger('model')
         self.precision = precision
         self.device = torch.device(device)
-        self._tdtype, self._op = _lib.op_dtype_of(precision)
+        # 'fp16x3': fp32 storage and attention as in 'fp32', every GEMM as one fp16 MFMA product over split operands
+        self.split = precision == _lib.SPLIT_PRECISION
+        self._tdtype, self._op = _lib.op_dtype_of("fp32" if self.split else precision)
         self.hidden_units = int(_cfg_get(config, "hidden_units"))
         self.num_blocks = int(_cfg_get(config, "num_blocks"))
         self.num_heads = int(_cfg_get(config, "num_heads"))
@@ -158,8 +160,15 @@ class Model(object):
             k = np.asarray(W[name + "/kernel"], np.float32)
             return k.reshape(k.shape[-2], k.shape[-1])            # conv kernels are [1,1,din,dout]
 
+        def mat(a):                                               # Wt[N][K] in the op dtype, or its [N][3K] split form
+            if self.split:
+                t = _lib.split3_weights(torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev))
+                keep.append(t)
+                return t
+            return dv(a, td)
+
         def dense(cd, name):
-            cd.w = ptr(dv(kernel2d(name).T, td))                  # Wt[N][K]
+            cd.w = ptr(mat(kernel2d(name).T))
             cd.b = ptr(dv(np.asarray(W[name + "/bias"], np.float32), torch.float32))
 
         def lnorm(cl, name):
@@ -168,17 +177,18 @@ class Model(object):
 
         c = _lib.Generator()
         c.op_dtype = self._op
+        c.gemm_split = 1 if self.split else 0
         c.d, c.heads, c.n_blocks = d, self.num_heads, self.num_blocks
         c.vocab_src, c.vocab_dst = self.src_vocab_size, self.dst_vocab_size
         c.emb_mult = float(np.float32(d ** 0.5)) if self.scale_embedding else 1.0     # model.py:494, 553
         if self.shared_embedding:
             shared = dv(np.asarray(W["embedding/shared/kernel"], np.float32), torch.float32)
             c.emb_src = c.emb_dst = ptr(shared)
-            c.softmax_w = ptr(dv(np.asarray(W["embedding/shared/kernel"], np.float32), td))
+            c.softmax_w = ptr(mat(np.asarray(W["embedding/shared/kernel"], np.float32)))
         else:
             c.emb_src = ptr(dv(np.asarray(W["embedding/src_embedding/kernel"], np.float32), torch.float32))
             c.emb_dst = ptr(dv(np.asarray(W["embedding/dst_embedding/kernel"], np.float32), torch.float32))
-            c.softmax_w = ptr(dv(np.asarray(W["embedding/softmax/kernel"], np.float32), td))
+            c.softmax_w = ptr(mat(np.asarray(W["embedding/softmax/kernel"], np.float32)))
         c.timing = ptr(dv(timing_signal(self.max_pos, d), torch.float32))
         c.max_pos = self.max_pos
         for i in range(self.num_blocks):
@@ -321,8 +331,11 @@ class Model(object):
         # operand copies: `opc` in the model's own op dtype (what get_reward / generate_step read); an fp16 model
         # runs its update step on a bf16 copy (`opc_train`): the backward pass keeps d(logits)-sized values in the
         # operand type and those underflow in fp16
-        opc = master.to(self._tdtype) if self.precision != "fp32" else None
-        opc_train = master.to(torch.bfloat16) if self.precision == "fp16" else opc
+        opc = master.to(self._tdtype) if self.precision not in ("fp32", _lib.SPLIT_PRECISION) else None
+        opc_train = master.to(torch.bfloat16) if self.precision in ("fp16", _lib.SPLIT_PRECISION) else opc
+        # split tier: the scoring struct reads a flat fp16 buffer with every matrix in its [N][3K] split form at three
+        # times its master offset (refreshed from the master after each update), the update step runs on the bf16 copy
+        spl = torch.zeros(3 * off, dtype=torch.float16, device=dev) if self.split else None
         old = self._c
 
         def put(struct, path, addr):
@@ -345,7 +358,14 @@ class Model(object):
             return c
 
         c = build(opc, self._op)
-        c_train = build(opc_train, _lib.NMTGAN_BF16) if self.precision == "fp16" else c
+        c_train = build(opc_train, _lib.NMTGAN_BF16) if self.precision in ("fp16", _lib.SPLIT_PRECISION) else c
+        if self.split:
+            c.gemm_split = 1
+            for name, kind, path, o, a in chunks:
+                if kind in ("mat", "smx"):
+                    put(c, path, spl.data_ptr() + 2 * 3 * o)
+                elif kind == "shr":
+                    c.softmax_w = spl.data_ptr() + 2 * 3 * o
         gc = _lib.Generator()
         for f in ("op_dtype", "d", "heads", "n_blocks", "vocab_src", "vocab_dst", "emb_mult", "timing", "max_pos"):
             setattr(gc, f, getattr(old, f))
@@ -356,13 +376,27 @@ class Model(object):
                 gc.emb_dst = gc.softmax_w = gc.emb_src
             index[name] = (kind, o, a.size)
         timing = [t for t in self._keep if t.data_ptr() == old.timing]
-        self._keep = timing + [master, grad, ms] + [t for t in (opc, opc_train) if t is not None]
+        self._keep = timing + [master, grad, ms] + [t for t in (opc, opc_train, spl) if t is not None]
         self._c = c
         self._train = dict(master=master, grad=grad, ms=ms, op=opc, op_train=opc_train, c_train=c_train,
-                           op_train_code=_lib.NMTGAN_BF16 if self.precision == "fp16" else self._op,
-                           gc=gc, index=index, shapes=shapes, n=off,
+                           op_train_code=_lib.NMTGAN_BF16 if self.precision in ("fp16", _lib.SPLIT_PRECISION) else self._op,
+                           gc=gc, index=index, shapes=shapes, n=off, split=spl,
                            loss=torch.zeros(1, dtype=torch.float32, device=dev), steps=0)
+        self._refresh_split()
         return self._train
+
+    def _refresh_split(self):
+        """Split tier: rebuild the [N][3K] fp16 form of every matrix and of the softmax table from the fp32 master."""
+        tr = self._train
+        if tr is None or tr.get("split") is None:
+            return
+        master, spl = tr["master"], tr["split"]
+        for name, (kind, o, n) in tr["index"].items():
+            if kind in ("mat", "smx", "shr"):
+                shp = tr["shapes"][name]
+                rows = shp[-1] if kind == "mat" else shp[0]        # Wt[N][K]: N = dout; tables are [V][d]
+                w = master[o:o + n].view(rows, n // rows)
+                spl[3 * o:3 * o + 3 * n].view(rows, 3 * (n // rows)).copy_(_lib.split3_weights(w))
 
     def get_weights(self) -> Dict[str, np.ndarray]:
         """Current trainable variables under their TF names and shapes (what tf.train.Saver would write)."""
@@ -447,6 +481,7 @@ class Model(object):
         if tr["op"] is not None and tr["op"] is not tr["op_train"]:        # fp16 scoring copy from the updated master
             check(lib.nmtgan_clip_values(ptr(tr["master"]), tr["n"], float("-inf"), float("inf"), ptr(tr["op"]), self._op, st),
                   "nmtgan_clip_values")
+        self._refresh_split()
         tr["steps"] += 1
         torch.cuda.synchronize(self.device)
         out = float(loss.item())

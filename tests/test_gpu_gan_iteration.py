@@ -10,7 +10,7 @@ from oracle import nmtgan_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16", "fp16x3"])
 def test_two_gan_iterations(cuda, tmp_path, precision):
     import nmt_gan_amd as N
     T, B, R = 10, 4, 2

@@ -142,10 +142,11 @@ def test_get_reward_no_bias_fp32(cuda, setup):
 
 # 16-bit tiers on the tiny near-uniform model (V = 512): (token agreement floor, P(real) abs error) as measured
 # on MI355X with margin; the benchmark-shape figures are asserted in test_gpu_precision_c2.py
-_TIER_BOUNDS = {"fp16": (0.995, 3e-3), "bf16": (0.92, 2e-2)}      # bf16 measured 0.933 (d512) - 0.988
+# fp16x3 = split-precision generator (fp32-class logits: only fp32-level near-ties may flip) with an fp16 discriminator
+_TIER_BOUNDS = {"fp16": (0.995, 3e-3), "bf16": (0.92, 2e-2), "fp16x3": (0.9995, 3e-3)}   # bf16 measured 0.933 (d512) - 0.988
 
 
-@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("precision", ["fp16", "bf16", "fp16x3"])
 @pytest.mark.parametrize("d,heads", [(64, 4), (128, 4), (256, 4), (512, 8)])
 def test_get_reward_16bit_token_agreement_and_rewards(cuda, d, heads, precision):
     """16-bit tiers: tokens checked per step under forced-identical prefixes - the oracle replays each

@@ -30,7 +30,8 @@ def test_ctypes_struct_sizes_match_header_layout():
     from nmt_gan_amd import _lib
     assert C.sizeof(_lib.Dense) == 16 and C.sizeof(_lib.Ln) == 16
     assert C.sizeof(_lib.EncBlock) == 6 * 16 and C.sizeof(_lib.DecBlock) == 10 * 16
-    assert C.sizeof(_lib.Generator) == 7 * 4 + 4 + 4 * 8 + 8 + 16 * (96 + 160)   # 7 ints+pad, 4 ptrs, max_pos+pad
+    # 7 ints+pad, 4 ptrs, max_pos+pad, the blocks, gemm_split+pad
+    assert C.sizeof(_lib.Generator) == 7 * 4 + 4 + 4 * 8 + 8 + 16 * (96 + 160) + 8
     assert C.sizeof(_lib.DiscTower) == 8 + 3 * 32 * 8 + 16
     assert C.sizeof(_lib.GemmArgs) % 8 == 0 and C.sizeof(_lib.RewardPlan) % 8 == 0
 
@@ -42,7 +43,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     pairs = {"nmtgan_gemm_args": (_lib.GemmArgs, "ln_out"), "nmtgan_embed_args": (_lib.EmbedArgs, "op_dtype"),
              "nmtgan_addln_args": (_lib.AddLnArgs, "zero_row"), "nmtgan_attn_args": (_lib.AttnArgs, "q_op_dtype"),
              "nmtgan_attn_group_args": (_lib.AttnGroupArgs, "kv_dtype"), "nmtgan_sample_args": (_lib.SampleArgs, "out"),
-             "nmtgan_generator": (_lib.Generator, "dec"), "nmtgan_discriminator": (_lib.Discriminator, "head_b"),
+             "nmtgan_generator": (_lib.Generator, "gemm_split"), "nmtgan_discriminator": (_lib.Discriminator, "head_b"),
              "nmtgan_reward_plan": (_lib.RewardPlan, "conv_bucket_taps"),
              "nmtgan_disc_tower_params": (_lib.DiscTowerParams, "hw_tr"), "nmtgan_disc_params": (_lib.DiscParams, "head_b")}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "nmtgan.h"', 'int main(void) {']
