@@ -105,7 +105,7 @@ int nmtgan_attn_group(const nmtgan_attn_group_args* a, void* stream) {
   return launch_attn_group(a, (hipStream_t)stream);
 }
 int nmtgan_transpose_v(const void* v, void* vt, int nblk, int len, int len_padded, int d, void* stream) {
-  return launch_transpose_v(v, vt, nblk, len, len_padded, d, (hipStream_t)stream);
+  return launch_transpose_v(v, vt, nblk, len, len_padded, d, 2, (hipStream_t)stream);
 }
 size_t nmtgan_logits_sample_workspace_bytes(int M, int V) { return (M > 0 && V > 0) ? logits_sample_workspace(M, V) : 0; }
 int nmtgan_logits_sample(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,

@@ -36,7 +36,7 @@ int launch_add_layernorm(const nmtgan_addln_args* a, hipStream_t st);
 int launch_attn_rows(const nmtgan_attn_args* a, hipStream_t st);
 int launch_sample_rows(const nmtgan_sample_args* a, hipStream_t st);
 int launch_attn_group(const nmtgan_attn_group_args* a, hipStream_t st);
-int launch_transpose_v(const void* v, void* vt, int nblk, int L, int Lp, int d, hipStream_t st);
+int launch_transpose_v(const void* v, void* vt, int nblk, int L, int Lp, int d, int esize, hipStream_t st);
 
 // rollout token bookkeeping (model.py:242-243, 250-252)
 int launch_init_rollouts(const int32_t* y, const int32_t* row_b, const int32_t* row_g, int n_rows, int T,

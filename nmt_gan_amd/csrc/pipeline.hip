@@ -556,8 +556,10 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   b.shV = ar.take(N * pre_rows * dm * es);
   // group attention path: 16-bit operands, <= 32 rollouts per (sentence, prefix) group, MFMA-friendly head dim
   const int dk = dm / g->heads;
-  b.group_R = (dtype_size(g->op_dtype) == 2 && p->rollnum <= 32 && (dk == 32 || dk == 64 || dk == 128) &&
-               p->n_steps >= 1) ? p->rollnum : 0;
+  // (the split-precision tier runs the fp32 form of the group kernel; the fp32 parity tier keeps the per-row kernel)
+  const bool group_dtype = dtype_size(g->op_dtype) == 2 ? (dk == 32 || dk == 64 || dk == 128)
+                                                        : (g->gemm_split && (dk == 32 || dk == 64));
+  b.group_R = (group_dtype && p->rollnum <= 32 && p->n_steps >= 1) ? p->rollnum : 0;
   b.Tp = (p->T + 31) / 32 * 32;
   b.Lsp = (p->Ls + 31) / 32 * 32;
   b.shVt = b.crossVt = nullptr;
@@ -684,9 +686,9 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
     const int es = dtype_size(op);
     for (int l = 0; l < g->n_blocks; ++l) {
       NMTGAN_TRY(launch_transpose_v(at(b.shV, (int64_t)l * B * T * dm, es), at(b.shVt, (int64_t)l * B * dm * b.Tp, es), B,
-                                    T, b.Tp, dm, st));
+                                    T, b.Tp, dm, es, st));
       NMTGAN_TRY(launch_transpose_v(at(b.crossV, (int64_t)l * B * Ls * dm, es),
-                                    at(b.crossVt, (int64_t)l * B * dm * b.Lsp, es), B, Ls, b.Lsp, dm, st));
+                                    at(b.crossVt, (int64_t)l * B * dm * b.Lsp, es), B, Ls, b.Lsp, dm, es, st));
     }
   }
   // Two-stream schedule: everything the discriminator does goes to `aux`; it only needs finished rollouts.
