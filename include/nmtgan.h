@@ -55,6 +55,8 @@ const char* nmtgan_last_error(void);
  * a_group_stride = T*E, K = w*E (a window is a contiguous slice of the [T,E] sentence image).
  * epilogue NMTGAN_EPI_LINEAR : v = (acc + bias[n]) * seg_scale[s]; relu optional; column segment
  *      s = n / seg_width goes to out[s] (row stride ldo[s], dtype out_f32[s] ? fp32 : op dtype).
+ *      out_f32[s] == 2: the segment is written as the split-precision operand image nmtgan_split3 makes of it,
+ *      fp16 [M][3 W] = [hi | lo | hi] with W = the segment's width and ldo[s] = 3 W (N % 64 == 0, 16-byte rows).
  * epilogue NMTGAN_EPI_CONVMAX: v = relu(acc*scale[n] + shift[n]) (conv bias + inference BN folded,
  *      cnn_discriminator.py:100-105,22-33); pooled[(r / a_group)*ld_pool + n] = max(., v) - the
  *      max over time of cnn_discriminator.py:469.  pooled must be >= 0 on entry (memset 0).
@@ -117,6 +119,7 @@ typedef struct {
   float* out_f32;            /* [M][d] */
   void* out_op;              /* [M][d] op dtype, may be NULL */
   int op_dtype;
+  void* out_split;           /* optional fp16 [M][3d]: the output as a split-precision GEMM operand (nmtgan_split3) */
 } nmtgan_embed_args;
 int nmtgan_embed(const nmtgan_embed_args* a, void* stream);
 
@@ -131,6 +134,7 @@ typedef struct {
   int M, d;
   float* out_f32; void* out_op; int op_dtype;
   const uint8_t* zero_row;
+  void* out_split;           /* optional fp16 [M][3d]: the output as a split-precision GEMM operand (nmtgan_split3) */
 } nmtgan_addln_args;
 int nmtgan_add_layernorm(const nmtgan_addln_args* a, void* stream);
 
@@ -168,6 +172,8 @@ typedef struct {
    * un-normalised o_init[M][d], m_init[M][heads], l_init[M][heads]; all three or none */
   const float* o_init; const float* m_init; const float* l_init;
   int q_op_dtype;            /* != 0: q is [M][d] in kv_dtype (as written by a GEMM output segment) instead of fp32 */
+  int out_split;             /* kv_dtype NMTGAN_F32 only, != 0: out is fp16 [M][3d], the split-precision operand image
+                              * of the fp32 result (what nmtgan_split3 would make of it) */
 } nmtgan_attn_args;
 int nmtgan_attn_rows(const nmtgan_attn_args* a, void* stream);
 
@@ -194,11 +200,16 @@ typedef struct {
    * served when 0 <= row0 < M, its rows are row0 .. row0+rows_per_group-1, its key count is cnt (len when
    * row_cnt is NULL).  row_blk / row_cnt are then only used as "counts present" flags. */
   const int32_t* slot_table; int slots; int n_entries;
-  int kv_dtype;              /* NMTGAN_BF16 (0) or NMTGAN_F16: element type of k, vt, out and of q when q_bf16 != 0 */
+  int kv_dtype;              /* NMTGAN_BF16 (0) or NMTGAN_F16: element type of k, vt, out and of q when q_bf16 != 0.
+                              * NMTGAN_F32: k, vt, q and out are all fp32 (q_bf16 is ignored), the products run on the
+                              * fp32 MFMA, head dim 32 or 64, every pointer 16-byte aligned */
+  int out_split;             /* NMTGAN_F32 with `out` only, != 0: out is fp16 [M][3d], the split-precision operand image */
 } nmtgan_attn_group_args;
 int nmtgan_attn_group(const nmtgan_attn_group_args* a, void* stream);
 /* v[nblk*len][d] -> vt[nblk][d][len_padded], 16-bit elements (bf16 or fp16), zero padded */
 int nmtgan_transpose_v(const void* v, void* vt, int nblk, int len, int len_padded, int d, void* stream);
+/* the same for fp32 values (the layout nmtgan_attn_group reads with kv_dtype NMTGAN_F32) */
+int nmtgan_transpose_v_f32(const float* v, float* vt, int nblk, int len, int len_padded, int d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Categorical sampler with injected uniforms.  Replaces softmax -> log -> tf.multinomial(.,1)

@@ -31,12 +31,13 @@ class EmbedArgs(C.Structure):
     _fields_ = [("table", vp), ("timing", vp), ("vocab", i32), ("max_pos", i32),
                 ("tok", vp), ("tok_ld", i64), ("tok_col", vp), ("tok_col_add", i32),
                 ("pos", vp), ("pos_mod", i32), ("pos_add", i32), ("mult", f32), ("M", i32), ("d", i32),
-                ("out_f32", vp), ("out_op", vp), ("op_dtype", i32)]
+                ("out_f32", vp), ("out_op", vp), ("op_dtype", i32), ("out_split", vp)]
 
 
 class AddLnArgs(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("M", i32), ("d", i32),
-                ("out_f32", vp), ("out_op", vp), ("op_dtype", i32), ("zero_row", vp)]
+                ("out_f32", vp), ("out_op", vp), ("op_dtype", i32), ("zero_row", vp),
+                ("out_split", vp)]
 
 
 class AttnArgs(C.Structure):
@@ -44,7 +45,8 @@ class AttnArgs(C.Structure):
                 ("k1", vp), ("v1", vp), ("len1", i32),
                 ("seg1_blk", vp), ("seg1_cnt", vp), ("rows_per_blk", i32), ("causal", i32), ("mask1", vp),
                 ("k2", vp), ("v2", vp), ("step_off", vp), ("n_steps2", i32), ("out", vp),
-                ("o_init", vp), ("m_init", vp), ("l_init", vp), ("q_op_dtype", i32)]
+                ("o_init", vp), ("m_init", vp), ("l_init", vp), ("q_op_dtype", i32),
+                ("out_split", i32)]
 
 
 class AttnGroupArgs(C.Structure):
@@ -52,7 +54,8 @@ class AttnGroupArgs(C.Structure):
                 ("k", vp), ("vt", vp), ("len", i32), ("len_padded", i32),
                 ("row_blk", vp), ("row_cnt", vp), ("mask", vp), ("out", vp),
                 ("o_part", vp), ("m_part", vp), ("l_part", vp), ("q_bf16", i32),
-                ("slot_table", vp), ("slots", i32), ("n_entries", i32), ("kv_dtype", i32)]
+                ("slot_table", vp), ("slots", i32), ("n_entries", i32), ("kv_dtype", i32),
+                ("out_split", i32)]
 
 
 class SampleArgs(C.Structure):
@@ -130,6 +133,7 @@ EXPORTS = {
     "nmtgan_logits_sample_static": (i32, [i32, vp, vp, i32, i32, i32, vp, vp, i64, vp, vp]),
     "nmtgan_attn_group": (i32, [C.POINTER(AttnGroupArgs), vp]),
     "nmtgan_transpose_v": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "nmtgan_transpose_v_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "nmtgan_disc_workspace_bytes": (sz, [C.POINTER(Discriminator), i32]),
     "nmtgan_disc_features": (i32, [C.POINTER(Discriminator), i32, vp, i32, vp, i32, vp, sz, vp]),
     "nmtgan_disc_head": (i32, [C.POINTER(Discriminator), vp, vp, vp, i32, vp, vp, vp]),

@@ -107,6 +107,9 @@ int nmtgan_attn_group(const nmtgan_attn_group_args* a, void* stream) {
 int nmtgan_transpose_v(const void* v, void* vt, int nblk, int len, int len_padded, int d, void* stream) {
   return launch_transpose_v(v, vt, nblk, len, len_padded, d, 2, (hipStream_t)stream);
 }
+int nmtgan_transpose_v_f32(const float* v, float* vt, int nblk, int len, int len_padded, int d, void* stream) {
+  return launch_transpose_v(v, vt, nblk, len, len_padded, d, 4, (hipStream_t)stream);
+}
 size_t nmtgan_logits_sample_workspace_bytes(int M, int V) { return (M > 0 && V > 0) ? logits_sample_workspace(M, V) : 0; }
 int nmtgan_logits_sample(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
                          const int64_t* u_off, int64_t u_add, int32_t* out, void* workspace,

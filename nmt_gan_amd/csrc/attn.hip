@@ -22,6 +22,7 @@ struct AttnParams {
   const void* k2; const void* v2; const int64_t* step_off; int n_steps2;
   void* out;
   const float* o_init; const float* m_init; const float* l_init;
+  int out_split;               // fp32 K/V only: out is the fp16 [M][3d] split-precision operand image of the result
 };
 
 template <typename KT, int EPL, int KB, typename QT>
@@ -111,6 +112,12 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
   const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
   for (int e = 0; e < EPL; ++e) o[e] *= inv;
+  if constexpr (sizeof(KT) == 4) {
+    if (p.out_split) {
+      store_split3<EPL>(reinterpret_cast<f16_t*>(p.out) + (int64_t)row * 3 * d + lane * EPL, d, o);
+      return;
+    }
+  }
   VecIO<KT, EPL>::store(reinterpret_cast<KT*>(p.out) + (int64_t)row * d + lane * EPL, o);
 }
 
@@ -244,6 +251,12 @@ __global__ __launch_bounds__(256) void attn_rows_16_kernel(AttnParams p) {
   const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
   for (int e = 0; e < EPL; ++e) o[e] *= inv;
+  if constexpr (sizeof(KT) == 4) {
+    if (p.out_split) {
+      store_split3<EPL>(reinterpret_cast<f16_t*>(p.out) + (int64_t)row * 3 * d + lane * EPL, d, o);
+      return;
+    }
+  }
   VecIO<KT, EPL>::store(reinterpret_cast<KT*>(p.out) + (int64_t)row * d + lane * EPL, o);
 }
 
@@ -285,7 +298,10 @@ int launch_attn_rows(const nmtgan_attn_args* a, hipStream_t st) {
   NMTGAN_REQUIRE((!a->o_init && !a->m_init && !a->l_init) || (a->o_init && a->m_init && a->l_init),
                  "attn: o_init/m_init/l_init must be given together");
   AttnParams p{a->q, a->M, a->d, a->heads, a->k1, a->v1, a->len1, a->seg1_blk, a->seg1_cnt, a->rows_per_blk,
-               a->causal, a->mask1, a->k2, a->v2, a->step_off, a->n_steps2, a->out, a->o_init, a->m_init, a->l_init};
+               a->causal, a->mask1, a->k2, a->v2, a->step_off, a->n_steps2, a->out, a->o_init, a->m_init, a->l_init,
+               a->out_split};
+  NMTGAN_REQUIRE(!a->out_split || (a->kv_dtype == NMTGAN_F32 && (uintptr_t)a->out % 16 == 0),
+                 "attn: out_split needs kv_dtype NMTGAN_F32 and a 16-byte aligned image");
   if (a->kv_dtype == NMTGAN_BF16) return a->q_op_dtype ? launch_attn_t<bf16_t, bf16_t>(p, st) : launch_attn_t<bf16_t, float>(p, st);
   if (a->kv_dtype == NMTGAN_F16) return a->q_op_dtype ? launch_attn_t<f16_t, f16_t>(p, st) : launch_attn_t<f16_t, float>(p, st);
   if (a->kv_dtype == NMTGAN_F32) return launch_attn_t<float, float>(p, st);

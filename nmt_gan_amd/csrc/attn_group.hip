@@ -35,6 +35,7 @@ struct GroupAttnParams {
   // slot form: workgroup e serves `slots` groups of ONE block of keys, table row e =
   // [blk, 0, row0[slots], cnt[slots]]; a slot is live when 0 <= row0 < M (its R rows are row0 .. row0+R-1)
   const int32_t* slot_table; int slots;
+  int out_split;               // fp32 kernel, final mode: out is the fp16 [M][3d] split-precision operand image
 };
 
 
@@ -320,7 +321,9 @@ __global__ __launch_bounds__(256) void attn_group_f32_kernel(GroupAttnParams p) 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       float v4[4] = {o[t][4 * c] * inv, o[t][4 * c + 1] * inv, o[t][4 * c + 2] * inv, o[t][4 * c + 3] * inv};
-      VecIO<float, 4>::store(dst + (int64_t)row * d + head * DK + 32 * t + 8 * c + 4 * h2, v4);
+      const int col = head * DK + 32 * t + 8 * c + 4 * h2;
+      if (p.out && p.out_split) store_split3<4>(reinterpret_cast<f16_t*>(p.out) + (int64_t)row * 3 * d + col, d, v4);
+      else VecIO<float, 4>::store(dst + (int64_t)row * d + col, v4);
     }
   if (!p.out && h2 == 0) {
     p.m_part[(int64_t)row * p.heads + head] = m;
@@ -370,7 +373,8 @@ int launch_attn_group(const nmtgan_attn_group_args* a, hipStream_t st) {
   NMTGAN_REQUIRE(a->out || (a->m_part && a->l_part), "attn_group: partial mode needs m_part and l_part");
   GroupAttnParams p{a->q, a->M, a->d, a->heads, a->rows_per_group, a->k, a->vt, a->len,
                     a->len_padded, a->row_blk, a->row_cnt, a->mask, a->out, a->o_part, a->m_part, a->l_part,
-                    a->slot_table, a->slots};
+                    a->slot_table, a->slots, a->out_split};
+  NMTGAN_REQUIRE(!a->out_split || (a->kv_dtype == NMTGAN_F32 && a->out), "attn_group: out_split needs NMTGAN_F32 and `out`");
   NMTGAN_REQUIRE(valid_op_dtype(a->kv_dtype), "attn_group: bad kv_dtype %d", a->kv_dtype);
   const bool half = a->kv_dtype == NMTGAN_F16;
   dim3 grid(a->slot_table ? a->n_entries : a->M / a->rows_per_group, (a->heads + 3) / 4), block(256);

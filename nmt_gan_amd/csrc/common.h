@@ -185,6 +185,22 @@ template <typename T, int N> struct VecIO16 {
 template <int N> struct VecIO<bf16_t, N> : VecIO16<bf16_t, N> {};
 template <int N> struct VecIO<f16_t, N> : VecIO16<f16_t, N> {};
 
+// N consecutive fp32 values as a split-precision GEMM operand: img points at the element's column inside an fp16
+// [rows][3K] image row; hi = fp16(v) goes to columns k and 2K + k, lo = fp16(v - hi) to K + k (what split3_kernel
+// writes, so a producer can emit the image itself)
+template <int N>
+__device__ __forceinline__ void store_split3(f16_t* img, int64_t K, const float (&v)[N]) {
+  float hi[N], lo[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    hi[e] = (float)(f16_t)v[e];
+    lo[e] = v[e] - hi[e];
+  }
+  VecIO<f16_t, N>::store(img, hi);
+  VecIO<f16_t, N>::store(img + K, lo);
+  VecIO<f16_t, N>::store(img + 2 * K, hi);
+}
+
 // 32x32x16 MFMA on 16-bit operands held as raw 16-byte register quads
 using f32x16_t = __attribute__((ext_vector_type(16))) float;
 template <typename T>

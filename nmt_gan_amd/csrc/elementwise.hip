@@ -40,11 +40,16 @@ __global__ __launch_bounds__(256) void embed_kernel(nmtgan_embed_args a) {
   const float* e = a.table + (int64_t)tok * a.d;
   const float* s = a.timing + (int64_t)pos * a.d;
   float* of = a.out_f32 + (int64_t)r * a.d;
-  OpT* oo = a.out_op ? reinterpret_cast<OpT*>(a.out_op) + (int64_t)r * a.d : nullptr;
+  OpT* oo = a.out_op && a.out_op != (void*)a.out_f32 ? reinterpret_cast<OpT*>(a.out_op) + (int64_t)r * a.d : nullptr;
+  f16_t* os = a.out_split ? reinterpret_cast<f16_t*>(a.out_split) + (int64_t)r * 3 * a.d : nullptr;
   for (int i = lane; i < a.d; i += 64) {
     const float v = e[i] * a.mult + s[i];
     of[i] = v;
     if (oo) OpTraits<OpT>::store(oo + i, v);
+    if (os) {
+      const float one[1] = {v};
+      store_split3<1>(os + i, a.d, one);
+    }
   }
 }
 
@@ -54,6 +59,7 @@ int launch_embed(const nmtgan_embed_args* a, hipStream_t st) {
   if (a->M == 0) return 0;
   NMTGAN_REQUIRE(a->M > 0 && a->d > 0 && a->vocab > 0 && a->max_pos > 0, "embed: bad shape");
   NMTGAN_REQUIRE(a->table && a->timing && a->tok && a->out_f32, "embed: null pointer");
+  NMTGAN_REQUIRE((uintptr_t)a->out_split % 16 == 0, "embed: out_split must be 16-byte aligned");
   dim3 grid((a->M + 3) / 4), block(256);
   NMTGAN_REQUIRE(valid_op_dtype(a->op_dtype), "embed: bad op_dtype %d", a->op_dtype);
   NMTGAN_DISPATCH_OP(a->op_dtype, OpT, hipLaunchKernelGGL(embed_kernel<OpT>, grid, block, 0, st, *a));
@@ -93,7 +99,8 @@ __global__ __launch_bounds__(256) void addln_kernel(nmtgan_addln_args a) {
 #pragma unroll
   for (int e = 0; e < EPL; ++e) v[e] = zero ? 0.f : (v[e] * rs) * g[e] + b[e];
   if (a.out_f32) VecIO<float, EPL>::store(a.out_f32 + base, v);
-  if (a.out_op) VecIO<OpT, EPL>::store(reinterpret_cast<OpT*>(a.out_op) + base, v);
+  if (a.out_op && a.out_op != (void*)a.out_f32) VecIO<OpT, EPL>::store(reinterpret_cast<OpT*>(a.out_op) + base, v);
+  if (a.out_split) store_split3<EPL>(reinterpret_cast<f16_t*>(a.out_split) + (int64_t)r * 3 * a.d + lane * EPL, a.d, v);
 }
 
 template <typename OpT>
@@ -118,6 +125,7 @@ int launch_add_layernorm(const nmtgan_addln_args* a, hipStream_t st) {
   NMTGAN_REQUIRE(a->M > 0 && a->d > 0 && a->d % 64 == 0, "add_layernorm: bad M=%d d=%d", a->M, a->d);
   NMTGAN_REQUIRE(a->x && a->gamma && a->beta && (a->out_f32 || a->out_op), "add_layernorm: null pointer");
   NMTGAN_REQUIRE(valid_op_dtype(a->op_dtype), "add_layernorm: bad op_dtype %d", a->op_dtype);
+  NMTGAN_REQUIRE((uintptr_t)a->out_split % 16 == 0, "add_layernorm: out_split must be 16-byte aligned");
   NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return launch_addln_t<OpT>(*a, st));
   return 0;
 }

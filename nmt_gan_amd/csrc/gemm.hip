@@ -144,7 +144,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MT][4
       const int nn = (p.n_seg > 1) ? n - seg * p.seg_width : n;
       const float sc = pick3(p.seg_scale, seg);
       const int64_t ldo = pick3(p.ldo, seg);
-      const bool of32 = pick3(p.out_f32, seg) != 0;
+      const int omode = pick3(p.out_f32, seg);   // 0 op dtype, 1 fp32, 2 split-precision operand image
+      const bool of32 = omode == 1;
+      const int64_t wimg = (p.n_seg > 1) ? p.seg_width : p.N;
       float* of = reinterpret_cast<float*>(pick3(p.out, seg));
       OpT* oo = reinterpret_cast<OpT*>(pick3(p.out, seg));
 #pragma unroll
@@ -156,7 +158,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MT][4
             float v = (acc[i][j][e] + bias) * sc;
             if (p.relu) v = fmaxf(v, 0.f);
             if (of32) of[(int64_t)m * ldo + nn] = v;
-            else OpTraits<OpT>::store(oo + (int64_t)m * ldo + nn, v);
+            else if (omode == 2) {
+              const float one[1] = {v};
+              store_split3<1>(reinterpret_cast<f16_t*>(oo) + (int64_t)m * ldo + nn, wimg, one);
+            } else OpTraits<OpT>::store(oo + (int64_t)m * ldo + nn, v);
           }
         }
       }
@@ -297,8 +302,12 @@ __global__ void splitk_finish_kernel(GemmParams p) {
   v = (v + (p.bias ? p.bias[n] : 0.f)) * pick3(p.seg_scale, seg);
   if (p.relu) v = fmaxf(v, 0.f);
   const int64_t ldo = pick3(p.ldo, seg);
-  if (pick3(p.out_f32, seg) != 0) reinterpret_cast<float*>(pick3(p.out, seg))[m * ldo + nn] = v;
-  else OpTraits<OpT>::store(reinterpret_cast<OpT*>(pick3(p.out, seg)) + m * ldo + nn, v);
+  const int omode = pick3(p.out_f32, seg);
+  if (omode == 1) reinterpret_cast<float*>(pick3(p.out, seg))[m * ldo + nn] = v;
+  else if (omode == 2) {
+    const float one[1] = {v};
+    store_split3<1>(reinterpret_cast<f16_t*>(pick3(p.out, seg)) + m * ldo + nn, (p.n_seg > 1) ? p.seg_width : p.N, one);
+  } else OpTraits<OpT>::store(reinterpret_cast<OpT*>(pick3(p.out, seg)) + m * ldo + nn, v);
 }
 
 // ------------------------------------------------------------------------------------------ pipelined kernel
@@ -336,7 +345,8 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
 // Needs N % 64 == 0, segment widths % 64 == 0 and 16-byte aligned output rows (checked at launch).
 template <typename OpT, int MT = 4>
 __device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x4 (&acc)[MT][4], int m0, int n0, int lane,
-                                              float* scr, bool f32_out, int seg, int nn0, const float* ev = nullptr) {
+                                              float* scr, bool f32_out, int seg, int nn0, const float* ev = nullptr,
+                                              bool split_out = false) {
   using O16 = std::conditional_t<sizeof(OpT) == 2, OpT, bf16_t>;     // 16-bit output type (never taken for fp32)
   const int fc = lane & 15, fq = lane >> 4;
   const float sc = pick3(p.seg_scale, seg);
@@ -370,8 +380,11 @@ __device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x4 (&acc)[
         const int r = lane >> 2;
         float x[8];
         VecIO<float, 8>::load(scr + r * 32 + 8 * (lane & 3), x);
-        if (mb + r < p.M)
-          VecIO<O16, 8>::store(reinterpret_cast<O16*>(outp) + (int64_t)(mb + r) * ldo + nn0 + jp * 32 + 8 * (lane & 3), x);
+        if (mb + r < p.M) {
+          const int64_t off = (int64_t)(mb + r) * ldo + nn0 + jp * 32 + 8 * (lane & 3);
+          if (split_out) store_split3<8>(reinterpret_cast<f16_t*>(outp) + off, (p.n_seg > 1) ? p.seg_width : p.N, x);
+          else VecIO<O16, 8>::store(reinterpret_cast<O16*>(outp) + off, x);
+        }
       }
     }
   }
@@ -489,7 +502,8 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
   for (int t = 0; t < my_tiles; ++t) {
     const bool has_next = t + 1 < my_tiles;
     for (int kt = 0; kt < nkt - 2; ++kt) {       // k-tile kt landed, kt+1 in flight, prefetch kt+2
-      if (kt < 2 && pend == 16) NMTGAN_WAIT(PNINST + 16);
+      if (kt < 2 && pend == 24) NMTGAN_WAIT(PNINST + 24);
+      else if (kt < 2 && pend == 16) NMTGAN_WAIT(PNINST + 16);
       else if (kt < 2 && pend == 8) NMTGAN_WAIT(PNINST + 8);
       else NMTGAN_WAIT(PNINST);
       step(true);
@@ -511,9 +525,10 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
       epilogue_stats(p, acc, m0, n0, lane);
     } else if (wide) {
       const int seg = (p.n_seg > 1) ? n0 / p.seg_width : 0;
-      const bool f32_out = pick3(p.out_f32, seg) != 0 || sizeof(OpT) == 4;
-      epilogue_wide<OpT>(p, acc, m0, n0, lane, scr, f32_out, seg, n0 - seg * p.seg_width);
-      if (tm * PBM + PBM <= p.M) pend = f32_out ? 16 : 8;      // every store instruction was issued
+      const int omode = pick3(p.out_f32, seg);
+      const bool f32_out = omode == 1 || sizeof(OpT) == 4;
+      epilogue_wide<OpT>(p, acc, m0, n0, lane, scr, f32_out, seg, n0 - seg * p.seg_width, nullptr, omode == 2);
+      if (tm * PBM + PBM <= p.M) pend = f32_out ? 16 : (omode == 2 ? 24 : 8);      // every store instruction was issued
     } else {
       epilogue<OpT, EPI>(p, acc, m0, n0, lane);
     }
@@ -550,7 +565,7 @@ static int launch_pipe(GemmParams p, hipStream_t st) {
     const int es = sizeof(OpT);
     bool ok = p.N % 64 == 0 && (p.n_seg == 1 || p.seg_width % 64 == 0);
     for (int s = 0; s < p.n_seg; ++s) {
-      const int oes = p.out_f32[s] ? 4 : es;
+      const int oes = p.out_f32[s] == 1 ? 4 : (p.out_f32[s] == 2 ? 2 : es);
       ok = ok && ((uintptr_t)p.out[s] % 16 == 0) && ((p.ldo[s] * oes) % 16 == 0);
     }
     p.wide_ok = ok ? 1 : 0;
@@ -803,8 +818,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmParams p) {
       epilogue_stats<8>(p, acc, m0, n0, lane);
     } else if (wide) {
       const int seg = (p.n_seg > 1) ? n0 / p.seg_width : 0;
-      const bool f32_out = pick3(p.out_f32, seg) != 0 || sizeof(OpT) == 4;
-      epilogue_wide<OpT, 8>(p, acc, m0, n0, lane, scr, f32_out, seg, n0 - seg * p.seg_width, use_ev ? ev : nullptr);
+      const int omode = pick3(p.out_f32, seg);
+      const bool f32_out = omode == 1 || sizeof(OpT) == 4;
+      epilogue_wide<OpT, 8>(p, acc, m0, n0, lane, scr, f32_out, seg, n0 - seg * p.seg_width, use_ev ? ev : nullptr,
+                            omode == 2);
     } else {
       epilogue<OpT, EPI, 8>(p, acc, m0, n0, lane, use_ev ? ev : nullptr);
     }
@@ -836,7 +853,7 @@ static int launch_p8(GemmParams p, hipStream_t st) {
     const int es = sizeof(OpT);
     bool ok = p.N % 64 == 0 && (p.n_seg == 1 || p.seg_width % 64 == 0);
     for (int s = 0; s < p.n_seg; ++s) {
-      const int oes = p.out_f32[s] ? 4 : es;
+      const int oes = p.out_f32[s] == 1 ? 4 : (p.out_f32[s] == 2 ? 2 : es);
       ok = ok && ((uintptr_t)p.out[s] % 16 == 0) && ((p.ldo[s] * oes) % 16 == 0);
     }
     p.wide_ok = ok ? 1 : 0;
@@ -1462,6 +1479,10 @@ static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
       p.out[s] = a->out[s]; p.ldo[s] = a->ldo[s]; p.out_f32[s] = a->out_f32[s];
       p.seg_scale[s] = a->seg_scale[s];
       if (s < a->n_seg) NMTGAN_REQUIRE(a->out[s] != nullptr, "gemm: null output segment %d", s);
+      if (s < a->n_seg && a->out_f32[s] == 2)
+        NMTGAN_REQUIRE(es == 2 && p.seg_width % 64 == 0 && a->ldo[s] >= 3 * (int64_t)p.seg_width && a->ldo[s] % 8 == 0 &&
+                           (uintptr_t)a->out[s] % 16 == 0,
+                       "gemm: a split-image segment needs a 16-bit op dtype, width %% 64 == 0 and 16-byte rows of >= 3 widths");
     }
     NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch<OpT, NMTGAN_EPI_LINEAR>(p, st));
   } else if (a->epilogue == NMTGAN_EPI_CONVMAX) {

@@ -37,7 +37,7 @@ static int split_operand(const void* A, int64_t lda, int M, int K, hipStream_t s
 // out[s] = (A . Wt^T + b) with up to 3 column segments
 static int dense(int op, const void* A, int64_t lda, int M, int K, int N, const nmtgan_dense& w, int n_seg,
                  int seg_width, void* const* outs, const int64_t* ldos, const int* out_f32, const float* scales,
-                 int relu, hipStream_t st) {
+                 int relu, hipStream_t st, const void* presplit = nullptr) {
   nmtgan_gemm_args a{};
   a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
   a.A = A; a.Wt = w.w; a.M = M; a.N = N; a.K = K; a.lda = lda; a.a_group = 0;
@@ -46,26 +46,28 @@ static int dense(int op, const void* A, int64_t lda, int M, int K, int N, const 
     a.out[s] = outs[s]; a.ldo[s] = ldos[s]; a.out_f32[s] = out_f32[s]; a.seg_scale[s] = scales ? scales[s] : 1.f;
   }
   if (g_split_buf && op == NMTGAN_F32) {           // w.w is fp16 [N][3K] = [hi | hi | lo]; outputs stay fp32
-    NMTGAN_TRY(split_operand(A, lda, M, K, st));
-    a.op_dtype = NMTGAN_F16; a.A = g_split_buf; a.lda = 3 * (int64_t)K; a.K = 3 * K;
-    for (int s = 0; s < n_seg; ++s) a.out_f32[s] = 1;
+    // presplit: the producer of A already wrote its [hi | lo | hi] image (add_layernorm, attention, the first
+    // feed-forward layer); else one pass over A makes it in the thread's scratch
+    if (!presplit) NMTGAN_TRY(split_operand(A, lda, M, K, st));
+    a.op_dtype = NMTGAN_F16; a.A = presplit ? presplit : g_split_buf; a.lda = 3 * (int64_t)K; a.K = 3 * K;
+    for (int s = 0; s < n_seg; ++s) a.out_f32[s] = out_f32[s] == 2 ? 2 : 1;    // 2: the consumer's operand image
   }
   return launch_gemm(&a, st);
 }
 static int dense1(int op, const void* A, int64_t lda, int M, int K, int N, const nmtgan_dense& w, void* out,
-                  int64_t ldo, int out_is_f32, float scale, int relu, hipStream_t st) {
+                  int64_t ldo, int out_is_f32, float scale, int relu, hipStream_t st, const void* presplit = nullptr) {
   void* outs[1] = {out};
   int64_t ld[1] = {ldo};
   int f[1] = {out_is_f32};
   float sc[1] = {scale};
-  return dense(op, A, lda, M, K, N, w, 1, N, outs, ld, f, sc, relu, st);
+  return dense(op, A, lda, M, K, N, w, 1, N, outs, ld, f, sc, relu, st, presplit);
 }
 
 static int add_ln(const nmtgan_generator* g, float* xf, const float* yf, const nmtgan_ln& ln, int M, void* xo,
-                  const uint8_t* zero_row, hipStream_t st) {
+                  const uint8_t* zero_row, hipStream_t st, void* x_img = nullptr) {
   nmtgan_addln_args a{};
   a.x = xf; a.y = yf; a.gamma = ln.g; a.beta = ln.b; a.M = M; a.d = g->d;
-  a.out_f32 = xf; a.out_op = xo; a.op_dtype = g->op_dtype; a.zero_row = zero_row;
+  a.out_f32 = xf; a.out_op = xo; a.op_dtype = g->op_dtype; a.zero_row = zero_row; a.out_split = x_img;
   return launch_add_layernorm(&a, st);
 }
 
@@ -76,7 +78,8 @@ static int add_ln(const nmtgan_generator* g, float* xf, const float* yf, const n
 // NMTGAN_FUSE_LN=2 fuses it too, 0 fuses nothing).  The split-K pipelines (B-row greedy decode) keep the two-kernel
 // form: their projections are cut into k-slices to fill the CUs.
 static int dense_add_ln(const nmtgan_generator* g, const void* A, int64_t lda, int M, int K, const nmtgan_dense& w,
-                        const nmtgan_ln& ln, float* xf, float* yf, void* xo, hipStream_t st) {
+                        const nmtgan_ln& ln, float* xf, float* yf, void* xo, hipStream_t st,
+                        const void* a_img = nullptr, void* x_img = nullptr) {
   static const int fuse = [] { const char* e = getenv("NMTGAN_FUSE_LN"); return e ? atoi(e) : 1; }();
   if (fuse > 0 && (K <= g->d || fuse > 1) && !gemm_splitk_active() && gemm_addln_supported(g->op_dtype, g->d, K)) {
     nmtgan_gemm_args a{};
@@ -85,9 +88,10 @@ static int dense_add_ln(const nmtgan_generator* g, const void* A, int64_t lda, i
     a.bias = w.b; a.ln_x = xf; a.ln_gamma = ln.g; a.ln_beta = ln.b; a.ln_out = xo;
     return launch_gemm(&a, st);
   }
-  NMTGAN_TRY(dense1(g->op_dtype, A, lda, M, K, g->d, w, yf, g->d, 1, 1.f, 0, st));
+  // split-precision form: a_img = A's operand image written by its producer, x_img = where to leave the image of x
+  NMTGAN_TRY(dense1(g->op_dtype, A, lda, M, K, g->d, w, yf, g->d, 1, 1.f, 0, st, a_img));
   prof::Hint own_class(-1);                      // the add_layernorm launch is timed under its own class
-  return add_ln(g, xf, yf, ln, M, xo, nullptr, st);
+  return add_ln(g, xf, yf, ln, M, xo, nullptr, st, x_img);
 }
 
 static int check_generator(const nmtgan_generator* g) {
@@ -106,16 +110,20 @@ static int check_generator(const nmtgan_generator* g) {
 struct Act {
   float* xf; void* xo; float* yf; float* q; void* ao; void* h;
   void* split; size_t split_bytes;            // split A operand of the widest GEMM (K = 4 d): rows x 12 d fp16
+  void* img;                                  // split-precision tier: [hi | lo | hi] image (rows x 3 d fp16) of the
+                                              // current d-wide GEMM operand (x after embed / LayerNorm, or the
+                                              // attention output), written by the kernel that produces it
 };
 static void carve_act(Arena& ar, int64_t rows, int d, int es, Act& a, bool gemm_split = false) {
   a.xf = ar.get<float>(rows * d);
-  a.xo = ar.take(rows * d * es);
+  a.xo = es == 4 ? (void*)a.xf : ar.take(rows * d * es);     // fp32 operands: the residual stream IS the GEMM operand
   a.yf = ar.get<float>(rows * d);
   a.q = ar.get<float>(rows * d);
   a.ao = ar.take(rows * d * es);
   a.h = ar.take(rows * 4 * d * es);
   a.split_bytes = gemm_split ? (size_t)rows * 12 * d * sizeof(f16_t) : 0;
   a.split = gemm_split ? ar.take(a.split_bytes) : nullptr;
+  a.img = gemm_split ? ar.take((size_t)rows * 3 * d * sizeof(f16_t)) : nullptr;
 }
 
 // ------------------------------------------------------------------------------------------ encoder
@@ -185,6 +193,11 @@ struct DecAttn {
 static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn& c, hipStream_t st) {
   const int op = g->op_dtype, d = g->d, es = dtype_size(op);
   const float qscale = 1.0f / sqrtf((float)(d / g->heads));
+  // Split-precision tier: every producer of a GEMM operand writes the operand's fp16 [hi | lo | hi] image itself
+  // (the embedding before this pass, add_layernorm, the attention kernels, the first feed-forward layer), so no
+  // stand-alone split pass runs between the layers.  a.img holds x's image when this function is entered and left.
+  void* const img = (g->gemm_split && g_split_buf) ? a.img : nullptr;
+  void* const attn_out = img ? img : a.ao;
   for (int l = 0; l < g->n_blocks; ++l) {
     const nmtgan_dec_block& b = g->dec[l];
     {
@@ -192,7 +205,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       int64_t ld[3] = {d, d, d};
       int f32[3] = {0, 0, 0};
       float sc[3] = {qscale, 1.f, 1.f};
-      NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st));
+      NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st, img));
     }
     if (c.group_R > 0) {
       // shared prefix keys once per group on MFMA -> running (o, m, l); private suffix per row after
@@ -208,7 +221,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       t.q = a.q; t.q_op_dtype = 1; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
       t.k2 = at(c.prK, l * c.pr_layer_stride, es); t.v2 = at(c.prV, l * c.pr_layer_stride, es);
       t.step_off = c.step_off; t.n_steps2 = c.n_steps2;
-      t.o_init = c.o_part; t.m_init = c.m_part; t.l_init = c.l_part; t.out = a.ao;
+      t.o_init = c.o_part; t.m_init = c.m_part; t.l_init = c.l_part; t.out = attn_out; t.out_split = img != nullptr;
       prof::Hint ph2(prof::ATTN_SELF_PRIVATE);
       NMTGAN_TRY(launch_attn_rows(&t, st));
     } else {
@@ -223,17 +236,18 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
         t.k2 = at(c.prK, l * c.pr_layer_stride, es); t.v2 = at(c.prV, l * c.pr_layer_stride, es);
         t.step_off = c.step_off; t.n_steps2 = c.n_steps2;
       }
-      t.out = a.ao;
+      t.out = attn_out; t.out_split = img != nullptr;
       prof::Hint ph(c.step_mode ? prof::ATTN_SELF : prof::ATTN_PREFILL);
       NMTGAN_TRY(launch_attn_rows(&t, st));
     }
-    NMTGAN_TRY(dense_add_ln(g, a.ao, d, M, d, b.o, b.ln0, a.xf, a.yf, a.xo, st));
-    NMTGAN_TRY(dense1(op, a.xo, d, M, d, d, b.cq, a.q, d, 0, qscale, 0, st));
+    NMTGAN_TRY(dense_add_ln(g, a.ao, d, M, d, b.o, b.ln0, a.xf, a.yf, a.xo, st, img, img));
+    NMTGAN_TRY(dense1(op, a.xo, d, M, d, d, b.cq, a.q, d, 0, qscale, 0, st, img));
     if (c.group_R > 0) {
       nmtgan_attn_group_args ga{};
       ga.q = a.q; ga.q_bf16 = 1; ga.kv_dtype = op; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
       ga.k = at(c.crossK, l * c.cross_layer_stride, es); ga.vt = at(c.crossVt, l * c.crosst_layer_stride, es);
-      ga.len = c.Ls; ga.len_padded = c.cross_Lp; ga.row_blk = c.cross_blk; ga.mask = c.x_pad; ga.out = a.ao;
+      ga.len = c.Ls; ga.len_padded = c.cross_Lp; ga.row_blk = c.cross_blk; ga.mask = c.x_pad;
+      ga.out = attn_out; ga.out_split = img != nullptr;
       ga.slot_table = c.slot_table; ga.slots = c.slots; ga.n_entries = c.n_entries;
       prof::Hint ph(prof::ATTN_CROSS);
       NMTGAN_TRY(launch_attn_group(&ga, st));
@@ -242,15 +256,21 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       t.q = a.q; t.q_op_dtype = 1; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
       t.k1 = at(c.crossK, l * c.cross_layer_stride, es); t.v1 = at(c.crossV, l * c.cross_layer_stride, es);
       t.len1 = c.Ls; t.seg1_blk = c.cross_blk; t.rows_per_blk = c.cross_rows_per_blk; t.causal = 0;
-      t.mask1 = c.x_pad; t.out = a.ao;
+      t.mask1 = c.x_pad; t.out = attn_out; t.out_split = img != nullptr;
       prof::Hint ph(c.step_mode ? prof::ATTN_CROSS : prof::ATTN_PREFILL);
       NMTGAN_TRY(launch_attn_rows(&t, st));
     }
-    NMTGAN_TRY(dense_add_ln(g, a.ao, d, M, d, b.co, b.ln1, a.xf, a.yf, a.xo, st));
+    NMTGAN_TRY(dense_add_ln(g, a.ao, d, M, d, b.co, b.ln1, a.xf, a.yf, a.xo, st, img, img));
     {
       prof::Hint ph(prof::GEMM_FFN);
-      NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
-      NMTGAN_TRY(dense_add_ln(g, a.h, 4 * d, M, 4 * d, b.ffn2, b.ln2, a.xf, a.yf, a.xo, st));
+      if (img) {                                   // hidden layer straight into its operand image [M][12 d]
+        NMTGAN_REQUIRE((size_t)M * 12 * d * sizeof(f16_t) <= a.split_bytes, "decoder: split scratch too small");
+        NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.split, 12 * (int64_t)d, 2, 1.f, 1, st, img));
+        NMTGAN_TRY(dense_add_ln(g, a.h, 4 * d, M, 4 * d, b.ffn2, b.ln2, a.xf, a.yf, a.xo, st, a.split, img));
+      } else {
+        NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
+        NMTGAN_TRY(dense_add_ln(g, a.h, 4 * d, M, 4 * d, b.ffn2, b.ln2, a.xf, a.yf, a.xo, st));
+      }
     }
   }
   return 0;
@@ -271,6 +291,7 @@ static int prefill(const nmtgan_generator* g, const int32_t* dec_in, const uint8
   e.table = g->emb_dst; e.timing = g->timing; e.vocab = g->vocab_dst; e.max_pos = g->max_pos;
   e.tok = dec_in; e.tok_ld = 1; e.pos_mod = T; e.mult = 2.0f * g->emb_mult;      // model.py:565 (quirk B.2)
   e.M = M; e.d = d; e.out_f32 = a.xf; e.out_op = a.xo; e.op_dtype = g->op_dtype;
+  e.out_split = (g->gemm_split && g_split_buf) ? a.img : nullptr;
   NMTGAN_TRY(launch_embed(&e, st));
   DecAttn c{};
   c.shK = shK; c.shV = shV; c.len_sh = T; c.sh_layer_stride = (int64_t)M * d; c.rows_per_blk = T; c.causal = 1;
@@ -784,6 +805,7 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
       e.tok = b.Y; e.tok_ld = T; e.tok_col = p->row_g; e.tok_col_add = step - 1;     // input token y_{g+s-1}
       e.pos = p->row_g; e.pos_add = step;                                            // position g+s
       e.mult = 2.0f * g->emb_mult; e.M = M; e.d = dm; e.out_f32 = b.act.xf; e.out_op = b.act.xo; e.op_dtype = op;
+      e.out_split = g->gemm_split ? b.act.img : nullptr;
       NMTGAN_TRY(launch_embed(&e, st));
       DecAttn c{};
       c.shK = b.shK; c.shV = b.shV; c.len_sh = T; c.sh_layer_stride = (int64_t)B * T * dm;
@@ -799,9 +821,9 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
         c.slot_table = p->grp_table; c.slots = p->grp_slots; c.n_entries = p->grp_live[step];
       }
       NMTGAN_TRY(decoder_pass(g, M, b.act, c, st));
-      if (b.fused && g->gemm_split) {    // the split operands through the fp16 form of the fused path: K = 3 d
-        NMTGAN_TRY(split_operand(b.act.xo, dm, M, dm, st));
-        NMTGAN_TRY(launch_logits_sample(NMTGAN_F16, g_split_buf, g->softmax_w, M, V, 3 * dm, p->uniforms, p->row_uoff, step,
+      if (b.fused && g->gemm_split) {    // the split operands through the fp16 form of the fused path: K = 3 d;
+                                         // the last add_layernorm of the pass left x's image in act.img
+        NMTGAN_TRY(launch_logits_sample(NMTGAN_F16, b.act.img, g->softmax_w, M, V, 3 * dm, p->uniforms, p->row_uoff, step,
                                         b.tok_cur, b.fused_ws, st));
       } else if (b.fused) {
         NMTGAN_TRY(launch_logits_sample(op, b.act.xo, g->softmax_w, M, V, dm, p->uniforms, p->row_uoff, step, b.tok_cur,
@@ -935,6 +957,7 @@ int generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* 
     else { e.tok = y + (i - 1); e.tok_ld = T; }
     e.pos_mod = 0; e.pos_add = i;
     e.mult = 2.0f * g->emb_mult; e.M = B; e.d = dm; e.out_f32 = b.act.xf; e.out_op = b.act.xo; e.op_dtype = op;
+    e.out_split = g->gemm_split ? b.act.img : nullptr;
     NMTGAN_TRY(launch_embed(&e, st));
     DecAttn c{};
     c.prK = b.prK; c.prV = b.prV; c.pr_layer_stride = (int64_t)T * B * dm; c.step_off = b.step_off; c.n_steps2 = i + 1;

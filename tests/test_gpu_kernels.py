@@ -586,3 +586,220 @@ def test_attn_group_slot_table(cuda, d, heads, R):
         for w_, g_ in zip(want, got):
             assert torch.equal(w_[:M_live], g_[:M_live])
             assert g_[M_live:].abs().max().item() == 0          # dead slots are not written
+
+
+@pytest.mark.parametrize("len1,Lp", [(50, 64), (80, 96)])
+@pytest.mark.parametrize("d,heads,R", [(128, 4, 16), (512, 8, 16), (128, 2, 3), (256, 8, 32), (256, 4, 8)])
+def test_attn_group_f32(cuda, d, heads, R, len1, Lp):
+    """fp32 form of the group attention (fp32 K / V^T / q, fp32 MFMA, fp32 output): normalised output
+    under a padding mask, the running state continued by attn_rows over private fp32 keys, and the slot
+    table giving exactly the one-group-per-workgroup result.  Tolerance 2e-5: fp32 products and sums."""
+    L = _lib()
+    g = torch.Generator().manual_seed(3 * d + R)
+    nblk = 3
+    slots = 32 // R
+    per_blk = 2 * slots + 1
+    G = nblk * per_blk
+    M = G * R
+    q = (torch.randn(M, d, generator=g) * 0.3).to(cuda)
+    k1 = torch.randn(nblk, len1, d, generator=g).to(cuda)
+    v1 = torch.randn(nblk, len1, d, generator=g).to(cuda)
+    vt = torch.full((nblk, d, Lp), float("nan"), device=cuda)
+    L.check(L.lib.nmtgan_transpose_v_f32(v1.data_ptr(), vt.data_ptr(), nblk, len1, Lp, d, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(vt[:, :, :len1], v1.transpose(1, 2)) and vt[:, :, len1:].abs().max().item() == 0
+    gblk = torch.arange(nblk, dtype=torch.int32).repeat_interleave(per_blk)
+    gcnt = torch.randint(1, len1 + 1, (G,), generator=g, dtype=torch.int32)
+    gcnt[0], gcnt[1], gcnt[2] = 1, 33, len1
+    blk = gblk.repeat_interleave(R).to(cuda)
+    cnt = gcnt.repeat_interleave(R).to(cuda)
+    mask = torch.zeros(nblk, len1, dtype=torch.uint8)
+    mask[:, len1 - 10:] = 1
+    mask[1, 0] = 1
+    mask_d = mask.to(cuda)
+    ents = []
+    for b in range(nblk):
+        gs = [b * per_blk + i for i in range(per_blk)]
+        for i in range(0, per_blk, slots):
+            part = gs[i:i + slots]
+            ents.append([b, 0] + [x * R for x in part] + [-1] * (slots - len(part))
+                        + [int(gcnt[x]) for x in part] + [0] * (slots - len(part)))
+    table = torch.tensor(ents, dtype=torch.int32).to(cuda)
+
+    def run(use_table, final):
+        a = L.AttnGroupArgs()
+        a.q, a.M, a.d, a.heads, a.rows_per_group, a.kv_dtype = q.data_ptr(), M, d, heads, R, L.NMTGAN_F32
+        a.k, a.vt, a.len, a.len_padded = k1.data_ptr(), vt.data_ptr(), len1, Lp
+        a.row_blk = blk.data_ptr()
+        out = torch.zeros(M, d, device=cuda)
+        o_part, m_part, l_part = torch.zeros(M, d, device=cuda), torch.zeros(M, heads, device=cuda), torch.zeros(M, heads, device=cuda)
+        if final:
+            a.mask, a.out = mask_d.data_ptr(), out.data_ptr()
+        else:
+            a.row_cnt = cnt.data_ptr()
+            a.o_part, a.m_part, a.l_part = o_part.data_ptr(), m_part.data_ptr(), l_part.data_ptr()
+        if use_table:
+            a.slot_table, a.slots, a.n_entries = table.data_ptr(), slots, table.shape[0]
+        L.check(L.lib.nmtgan_attn_group(C.byref(a), L.stream_ptr()))
+        torch.cuda.synchronize()
+        return out, o_part, m_part, l_part
+
+    def ref_row(r, final, extra_k=None, extra_v=None):
+        b = int(blk[r])
+        keep = [j for j in range(len1) if not int(mask[b, j])] if final else list(range(int(cnt[r])))
+        ks, vs = [k1[b, j] for j in keep], [v1[b, j] for j in keep]
+        if extra_k is not None:
+            ks += extra_k
+            vs += extra_v
+        return _attn_ref(q[r].double().cpu(), torch.stack(ks).double().cpu(), torch.stack(vs).double().cpu(), heads)
+
+    out = run(False, True)[0]
+    for r in range(0, M, 3):
+        err = (out[r].double().cpu() - ref_row(r, True)).abs().max().item()
+        assert err < 2e-5, (r, err)
+    part = run(False, False)
+    nsteps = 3
+    step_off = torch.tensor([0, M, 2 * M, 3 * M], dtype=torch.int64, device=cuda)
+    k2 = torch.randn(nsteps * M, d, generator=g).to(cuda)
+    v2 = torch.randn(nsteps * M, d, generator=g).to(cuda)
+    out2 = torch.empty(M, d, device=cuda)
+    b = L.AttnArgs()
+    b.q, b.M, b.d, b.heads, b.kv_dtype = q.data_ptr(), M, d, heads, L.NMTGAN_F32
+    b.k2, b.v2, b.step_off, b.n_steps2 = k2.data_ptr(), v2.data_ptr(), step_off.data_ptr(), nsteps
+    b.o_init, b.m_init, b.l_init, b.out = part[1].data_ptr(), part[2].data_ptr(), part[3].data_ptr(), out2.data_ptr()
+    L.check(L.lib.nmtgan_attn_rows(C.byref(b), L.stream_ptr()))
+    torch.cuda.synchronize()
+    for r in range(0, M, 5):
+        ek = [k2[s * M + r] for s in range(nsteps)]
+        ev = [v2[s * M + r] for s in range(nsteps)]
+        err = (out2[r].double().cpu() - ref_row(r, False, ek, ev)).abs().max().item()
+        assert err < 2e-5, (r, err)
+    for final in (True, False):
+        want, got = run(False, final), run(True, final)
+        for w_, g_ in zip(want, got):
+            assert torch.equal(w_, g_)
+    # head dims the fp32 kernel does not serve are refused
+    a = L.AttnGroupArgs()
+    a.q, a.M, a.d, a.heads, a.rows_per_group, a.kv_dtype = q.data_ptr(), M, d, 1, R, L.NMTGAN_F32
+    a.k, a.vt, a.len, a.len_padded, a.row_blk, a.out = k1.data_ptr(), vt.data_ptr(), len1, Lp, blk.data_ptr(), out.data_ptr()
+    assert L.lib.nmtgan_attn_group(C.byref(a), L.stream_ptr()) != 0
+
+
+def _split3_ref(x):
+    """[hi | lo | hi] fp16 image of an fp32 matrix, the host formula of nmtgan_split3."""
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    return torch.cat([hi, lo, hi], dim=1)
+
+
+@pytest.mark.parametrize("M,N,K,relu,bias", [(300, 512, 512, 0, 1), (4097, 2048, 512, 1, 1), (70000, 2048, 1536, 1, 1),
+                                             (16, 2048, 1536, 1, 0), (2600, 512, 6144, 0, 1)])
+def test_gemm_split_image_output(cuda, M, N, K, relu, bias):
+    """out_f32 = 2: the GEMM writes its result as the [hi | lo | hi] operand image of the next split-precision GEMM.
+    Bit-identical to nmtgan_split3 of the same GEMM's fp32 output, on every kernel the shapes dispatch to (the
+    double-buffered 128x128, the persistent 256x128 and 256x256 kernels)."""
+    L = _lib()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.7).half().to(cuda)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(cuda)
+    b = torch.randn(N, generator=g).to(cuda) if bias else None
+
+    def run(mode):
+        a = L.GemmArgs()
+        a.op_dtype, a.epilogue, a.A, a.Wt, a.M, a.N, a.K, a.lda = L.NMTGAN_F16, L.EPI_LINEAR, A.data_ptr(), W.data_ptr(), M, N, K, K
+        a.bias, a.relu, a.n_seg, a.seg_width = (b.data_ptr() if bias else None), relu, 1, N
+        out = torch.full((M, 3 * N), float("nan"), device=cuda, dtype=torch.float16) if mode == 2 else torch.empty(M, N, device=cuda)
+        a.out[0], a.ldo[0], a.out_f32[0], a.seg_scale[0] = out.data_ptr(), (3 * N if mode == 2 else N), mode, 1.0
+        L.check(L.lib.nmtgan_gemm(C.byref(a), L.stream_ptr()), "gemm")
+        torch.cuda.synchronize()
+        return out
+
+    f32 = run(1)
+    img = run(2)
+    assert torch.equal(img, _split3_ref(f32))
+    # two segments: fp32 and an image
+    if N != 512:
+        return
+    a = L.GemmArgs()
+    w = N // 2
+    a.op_dtype, a.epilogue, a.A, a.Wt, a.M, a.N, a.K, a.lda = L.NMTGAN_F16, L.EPI_LINEAR, A.data_ptr(), W.data_ptr(), M, N, K, K
+    a.bias, a.relu, a.n_seg, a.seg_width = (b.data_ptr() if bias else None), relu, 2, w
+    o0 = torch.empty(M, w, device=cuda)
+    o1 = torch.full((M, 3 * w), float("nan"), device=cuda, dtype=torch.float16)
+    a.out[0], a.ldo[0], a.out_f32[0], a.seg_scale[0] = o0.data_ptr(), w, 1, 1.0
+    a.out[1], a.ldo[1], a.out_f32[1], a.seg_scale[1] = o1.data_ptr(), 3 * w, 2, 1.0
+    L.check(L.lib.nmtgan_gemm(C.byref(a), L.stream_ptr()), "gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(o0, f32[:, :w]) and torch.equal(o1, _split3_ref(f32[:, w:].contiguous()))
+
+
+@pytest.mark.parametrize("d,heads", [(64, 4), (256, 4), (512, 8), (1024, 16)])
+def test_split_image_producers(cuda, d, heads):
+    """embed, add_layernorm, attn_rows (fp32) and attn_group (fp32) writing the split-precision operand image of
+    their output: bit-identical to nmtgan_split3 applied to the fp32 output of the same call."""
+    L = _lib()
+    g = torch.Generator(device="cpu").manual_seed(d)
+    M, V, P = 203, 97, 60
+    # embed
+    table, timing = torch.randn(V, d, generator=g).to(cuda), torch.randn(P, d, generator=g).to(cuda)
+    tok = torch.randint(0, V, (M,), generator=g, dtype=torch.int32).to(cuda)
+    e = L.EmbedArgs()
+    e.table, e.timing, e.vocab, e.max_pos, e.tok, e.tok_ld, e.pos_mod, e.mult = table.data_ptr(), timing.data_ptr(), V, P, tok.data_ptr(), 1, P, 3.0
+    xf = torch.empty(M, d, device=cuda)
+    img = torch.full((M, 3 * d), float("nan"), device=cuda, dtype=torch.float16)
+    e.M, e.d, e.out_f32, e.op_dtype, e.out_split = M, d, xf.data_ptr(), L.NMTGAN_F32, img.data_ptr()
+    L.check(L.lib.nmtgan_embed(C.byref(e), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(img, _split3_ref(xf))
+    # add_layernorm, in place on x with the op-dtype copy aliased to it (the fp32 tiers' layout)
+    y = torch.randn(M, d, generator=g).to(cuda)
+    gam, bet = torch.randn(d, generator=g).to(cuda), torch.randn(d, generator=g).to(cuda)
+    a = L.AddLnArgs()
+    a.x, a.y, a.gamma, a.beta, a.M, a.d = xf.data_ptr(), y.data_ptr(), gam.data_ptr(), bet.data_ptr(), M, d
+    a.out_f32, a.out_op, a.op_dtype, a.out_split = xf.data_ptr(), xf.data_ptr(), L.NMTGAN_F32, img.data_ptr()
+    want = torch.nn.functional.layer_norm((xf + y).double(), (d,), gam.double(), bet.double(), 1e-6)
+    L.check(L.lib.nmtgan_add_layernorm(C.byref(a), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert (xf.double() - want).abs().max().item() < 1e-4
+    assert torch.equal(img, _split3_ref(xf))
+    # attn_rows, fp32 keys: private segment of 5 steps
+    nsteps = 5
+    q = (torch.randn(M, d, generator=g) * 0.3).to(cuda)
+    k2, v2 = torch.randn(nsteps * M, d, generator=g).to(cuda), torch.randn(nsteps * M, d, generator=g).to(cuda)
+    step_off = (torch.arange(nsteps + 1, dtype=torch.int64) * M).to(cuda)
+    outs = []
+    for split in (0, 1):
+        o = torch.full((M, 3 * d), float("nan"), device=cuda, dtype=torch.float16) if split else torch.empty(M, d, device=cuda)
+        b = L.AttnArgs()
+        b.q, b.M, b.d, b.heads, b.kv_dtype, b.out_split = q.data_ptr(), M, d, heads, L.NMTGAN_F32, split
+        b.k2, b.v2, b.step_off, b.n_steps2, b.out = k2.data_ptr(), v2.data_ptr(), step_off.data_ptr(), nsteps, o.data_ptr()
+        L.check(L.lib.nmtgan_attn_rows(C.byref(b), L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[1], _split3_ref(outs[0]))
+    b.kv_dtype, b.out_split = L.NMTGAN_F16, 1                  # only the fp32 form has the image output
+    assert L.lib.nmtgan_attn_rows(C.byref(b), L.stream_ptr()) != 0
+    # attn_group, fp32, normalised output
+    if d // heads not in (32, 64):
+        return
+    R, nblk, len1, Lp = 16, 3, 50, 64
+    Mg = 12 * R
+    qg = (torch.randn(Mg, d, generator=g) * 0.3).to(cuda)
+    k1, v1 = torch.randn(nblk, len1, d, generator=g).to(cuda), torch.randn(nblk, len1, d, generator=g).to(cuda)
+    vt = torch.empty(nblk, d, Lp, device=cuda)
+    L.check(L.lib.nmtgan_transpose_v_f32(v1.data_ptr(), vt.data_ptr(), nblk, len1, Lp, d, L.stream_ptr()))
+    blk = torch.randint(0, nblk, (12,), generator=g, dtype=torch.int32).repeat_interleave(R).to(cuda)
+    mask = torch.zeros(nblk, len1, dtype=torch.uint8)
+    mask[:, 44:] = 1
+    mask_d = mask.to(cuda)
+    outs = []
+    for split in (0, 1):
+        o = torch.full((Mg, 3 * d), float("nan"), device=cuda, dtype=torch.float16) if split else torch.empty(Mg, d, device=cuda)
+        ga = L.AttnGroupArgs()
+        ga.q, ga.M, ga.d, ga.heads, ga.rows_per_group, ga.kv_dtype = qg.data_ptr(), Mg, d, heads, R, L.NMTGAN_F32
+        ga.k, ga.vt, ga.len, ga.len_padded = k1.data_ptr(), vt.data_ptr(), len1, Lp
+        ga.row_blk, ga.mask, ga.out, ga.out_split = blk.data_ptr(), mask_d.data_ptr(), o.data_ptr(), split
+        L.check(L.lib.nmtgan_attn_group(C.byref(ga), L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[1], _split3_ref(outs[0]))
