@@ -89,7 +89,7 @@ def algorithmic_work(cfg, plan, B, Ls, es):
     }
 
 
-PROFILE_TAG = {"fp16": "r2_c2_fp16", "bf16": "r1_c2_bf16"}     # committed PMC summaries under profiles/
+PROFILE_TAG = {"fp16": "r2_c2_fp16", "bf16": "r1_c2_bf16", "fp16x3": "r2_c2_fp16x3"}     # committed PMC summaries under profiles/
 # kernel classes -> kernels of the PMC summary (template argument 2 of the GEMM kernels is the epilogue; the element
 # type prints as `unsigned short` for bf16 and `_Float16` for fp16)
 TRAFFIC_KERNELS = {
@@ -177,7 +177,24 @@ def cpu_baseline(cfg, Wg, Wd, x, y, seed_u):
     b, a = np.polyfit(n, t, 1) if len(pts) > 1 else (t[0] / n[0], 0.0)
     per_roll = sum(a + b * (T - g) for g in range(1, T))
     total = R * per_roll
+    # the same sample through the oracle's KV-cached (incremental) decoding: separates what the restructuring
+    # buys on the same cores from what the GPU buys
+    pts_i = []
+    t_inc = time.perf_counter()
+    with torch.no_grad():
+        for g in gs:
+            t0 = time.perf_counter()
+            O.get_reward(W32, gcfg, Wd32, dcfg, xs, xp, ys, mask, 1, T, 0.6, u, mode="incremental", pairs={(0, g)})
+            pts_i.append((T - g, time.perf_counter() - t0))
+    elapsed_i = time.perf_counter() - t_inc
+    ni = np.array([p[0] for p in pts_i], np.float64)
+    ti = np.array([p[1] for p in pts_i], np.float64)
+    bi, ai = np.polyfit(ni, ti, 1) if len(pts_i) > 1 else (ti[0] / ni[0], 0.0)
+    total_i = R * sum(ai + bi * (T - g) for g in range(1, T))
     return {"value": Bc / total, "unit": "rollout-scored sentences/s", "cores": torch.get_num_threads(),
+            "incremental_value": Bc / total_i,
+            "incremental_sample": "the same pairs through the oracle's KV-cached decoding (%.1f s measured; each timed "
+                                  "call re-runs the encoder and the source tower once)" % elapsed_i,
             "kind": "port",
             "sample": "oracle structure-faithful fp32 torch-CPU, %d sentences, 1 roll, give_num in %s "
                       "(%.1f s measured), linear fit in sampled steps, extrapolated to rollnum %d x %d prefixes"
