@@ -51,7 +51,7 @@ def _build_setup(d, heads):
                 ref_r=ref_r, ref_rolls=ref_rolls)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("fp16", 4e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("fp16x3", 1e-5), ("fp16", 4e-3), ("bf16", 3e-2)])
 def test_teacher_forced_logits(cuda, setup, precision, tol):
     s = setup
     m, _ = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], precision, T)
@@ -82,9 +82,12 @@ def test_discriminator_forward(cuda, setup, precision, tol):
     assert err < tol, err
 
 
-def test_greedy_generate_fp32(cuda, setup):
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_greedy_generate_fp32(cuda, setup, precision):
+    """Greedy ids against the fp64 oracle: the exact tier and the split-precision tier (its B-row decode steps run the
+    split-K form of every GEMM, the hidden layer's operand image written by the split-K finish kernel)."""
     s = setup
-    m, _ = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], "fp32", T)
+    m, _ = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], precision, T)
     got = m.generate_step(s["x"])
     ref = O.generate_step(s["W64"], s["gcfg"], torch.from_numpy(s["x"]).long(), T)
     assert got.dtype == np.int32 and got.shape == (B, T)
