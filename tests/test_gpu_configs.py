@@ -104,10 +104,11 @@ def _reward_tail(plan, p_rows, p_base, mask, R, bias):
     return ((q - np.float32(bias * R)) * mask) / np.float32(R)
 
 
-def test_c4_big_model_properties(cuda):
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3"])
+def test_c4_big_model_properties(cuda, precision):
     D, BLOCKS, HEADS, V, E, T, R, B = 1024, 6, 16, 32000, 512, 80, 20, 8
     from nmt_gan_amd import synthetic
-    N, m, disc, Wd = _facade_pair(D, BLOCKS, HEADS, V, E, T, B, "fp16")
+    N, m, disc, Wd = _facade_pair(D, BLOCKS, HEADS, V, E, T, B, precision)
     x, y = synthetic.synthetic_batch(B, T, V, V, seed=404)
     y[1, 33] = O.EOS_ID
     y[6, 3] = O.EOS_ID
