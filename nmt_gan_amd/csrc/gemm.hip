@@ -355,6 +355,47 @@ __device__ __forceinline__ void epilogue_wide(const GemmParams& p, f32x4 (&acc)[
   float bias[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bias[j] = ev ? ev[j * 16 + fc] : (p.bias ? p.bias[n0 + j * 16 + fc] : 0.f);
+  if (!f32_out && p.wide_ok == 2) {
+    // 16-bit outputs: pieces of 8 rows x all 64 columns of the wave tile, so that a store instruction writes whole
+    // 128-byte row segments (8 lanes x 16 bytes per row) instead of 64-byte halves.  v_permlane32_swap regroups the
+    // values first: column tiles j and j + 2 trade their lane halves, after which EVERY lane holds values of the
+    // piece's 8 rows (lanes 0-31 columns 0-31, lanes 32-63 columns 32-63; row 4 ((lane >> 4) & 1) + e) and all 64
+    // lanes write.  Row r keeps column c at c ^ 16 ((r >> 2) & 1): the 64 lanes of a write hit 64 different banks.
+    const int64_t wimg = (p.n_seg > 1) ? p.seg_width : p.N;
+    const int g2 = lane >> 5, fq1 = fq & 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      unsigned ph[2][2][4];                        // [half h][jj][e]
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = (acc[i][jj][e] + bias[jj]) * sc, b = (acc[i][jj + 2][e] + bias[jj + 2]) * sc;
+          if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+          const u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+          ph[0][jj][e] = sw[0];
+          ph[1][jj][e] = sw[1];
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            scr[(4 * fq1 + e) * 64 + ((32 * g2 + 16 * jj + fc) ^ (fq1 << 4))] = __uint_as_float(ph[h][jj][e]);
+        const int r = lane >> 3;
+        float x[8];
+        VecIO<float, 8>::load(scr + r * 64 + ((8 * (lane & 7)) ^ (((r >> 2) & 1) << 4)), x);
+        const int m = m0 + i * 16 + 8 * h + r;
+        if (m < p.M) {
+          const int64_t off = (int64_t)m * ldo + nn0 + 8 * (lane & 7);
+          if (split_out) store_split3<8>(reinterpret_cast<f16_t*>(outp) + off, wimg, x);
+          else VecIO<O16, 8>::store(reinterpret_cast<O16*>(outp) + off, x);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -568,8 +609,8 @@ static int launch_pipe(GemmParams p, hipStream_t st) {
       const int oes = p.out_f32[s] == 1 ? 4 : (p.out_f32[s] == 2 ? 2 : es);
       ok = ok && ((uintptr_t)p.out[s] % 16 == 0) && ((p.ldo[s] * oes) % 16 == 0);
     }
-    p.wide_ok = ok ? 1 : 0;
-    if (const char* e = getenv("NMTGAN_GEMM_WIDE")) p.wide_ok = p.wide_ok && atoi(e);
+    p.wide_ok = ok ? 2 : 0;
+    if (const char* e = getenv("NMTGAN_GEMM_WIDE")) p.wide_ok = p.wide_ok ? atoi(e) : 0;
   }
   const int nwg = p.ntm * p.ntn;
   const int grid = persistent_grid(nwg);         // one block per CU; the tile walk is bijective for any grid
@@ -856,7 +897,8 @@ static int launch_p8(GemmParams p, hipStream_t st) {
       const int oes = p.out_f32[s] == 1 ? 4 : (p.out_f32[s] == 2 ? 2 : es);
       ok = ok && ((uintptr_t)p.out[s] % 16 == 0) && ((p.ldo[s] * oes) % 16 == 0);
     }
-    p.wide_ok = ok ? 1 : 0;
+    p.wide_ok = ok ? 2 : 0;
+    if (const char* e = getenv("NMTGAN_GEMM_WIDE")) p.wide_ok = p.wide_ok ? atoi(e) : 0;
   }
   const int nwg = p.ntm * p.ntn;
   const int grid = persistent_grid(nwg);
