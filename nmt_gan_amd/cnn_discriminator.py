@@ -39,7 +39,7 @@ class DisCNN(object):
                  source_data=None, vocab_size_s=None, dev_positive_data=None, dev_negative_data=None,
                  dev_source_data=None, max_epoches=10, dispFreq=1, saveFreq=10, devFreq=1000, clip_c=1.0,
                  optimizer='adadelta', saveto='discriminator', reload=False, reshuffle=False, l2_reg_lambda=0.0,
-                 scope='discnn', init_device="/cpu:0", reuse_var=False, precision="bf16", device="cuda:0",
+                 scope='discnn', init_device="/cpu:0", reuse_var=False, precision="fp16", device="cuda:0",
                  chunk_rows=4096):
         if num_classes != 2:
             raise ValueError("the reward path reads P(real) of a 2-way softmax (model.py:315); num_classes must be 2")

@@ -66,7 +66,7 @@ class _Saver(object):
 
 
 class Model(object):
-    def __init__(self, config, graph=None, sess=None, precision="bf16", device="cuda:0", max_pos=256):
+    def __init__(self, config, graph=None, sess=None, precision="fp16", device="cuda:0", max_pos=256):
         self.graph = graph
         self.sess = sess
         self.config = config
