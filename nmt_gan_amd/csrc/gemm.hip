@@ -888,7 +888,10 @@ static int launch_p8(GemmParams p, hipStream_t st) {
   }
   p.ntm = (p.M + QBM - 1) / QBM;
   p.ntn = (p.N + QBN - 1) / QBN;
-  p.group_m = 2;
+  // tile groups of 2 row tiles (4 are as fast); the logits GEMM (rows = vocabulary) takes 8: an XCD then keeps 2 MiB
+  // of the table in its L2 and sweeps the activations twice instead of eight times - same time, a third of the
+  // fetches past the L2
+  p.group_m = EPI == EPI_STATS ? 8 : 2;
   if (const char* e = getenv("NMTGAN_GEMM_GM")) p.group_m = atoi(e);
   if constexpr (EPI == NMTGAN_EPI_LINEAR) {
     const int es = sizeof(OpT);
