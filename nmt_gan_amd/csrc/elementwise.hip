@@ -166,6 +166,20 @@ int launch_split3(const float* A, int64_t lda, int M, int K, void* out, hipStrea
   return 0;
 }
 
+// x <- float(fp16(x)): what a value keeps when it is stored in the fp16 tiers' caches (error-budget runs of the
+// split-precision tier, NMTGAN_SPLIT_ABLATE)
+__global__ void round_f16_kernel(float* x, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = (float)(f16_t)x[i];
+}
+int launch_round_f16(float* x, int64_t n, hipStream_t st) {
+  prof::Scope prof_scope(prof::OTHER, st);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(round_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n);
+  NMTGAN_CHECK_LAUNCH("round_f16");
+  return 0;
+}
+
 // ------------------------------------------------------------------ rollout tokens
 // Y[row][t] = y[b][t] for t < g else 0 (model.py:250-252: given_y = Y[:, :given_num], zero padded)
 __global__ void init_rollouts_kernel(const int32_t* y, const int32_t* row_b, const int32_t* row_g, int n_rows, int T,

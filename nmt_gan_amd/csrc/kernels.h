@@ -31,6 +31,7 @@ size_t logits_sample_workspace(int M, int V);
 int launch_logits_sample_static(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
                                 const int64_t* u_off, int64_t u_add, int32_t* out, hipStream_t st);
 int launch_zero(void* p, size_t bytes, hipStream_t st);      // fill kernel (16-byte aligned buffer); no memset nodes
+int launch_round_f16(float* x, int64_t n, hipStream_t st);   // x <- float(fp16(x)) in place (error-budget runs only)
 int launch_embed(const nmtgan_embed_args* a, hipStream_t st);
 int launch_add_layernorm(const nmtgan_addln_args* a, hipStream_t st);
 int launch_attn_rows(const nmtgan_attn_args* a, hipStream_t st);

@@ -34,6 +34,16 @@ static int split_operand(const void* A, int64_t lda, int M, int K, hipStream_t s
   return launch_split3((const float*)A, lda, M, K, g_split_buf, st);
 }
 
+// Error budget of the 16-bit tiers, measured from the split-precision tier by taking the precision away from ONE
+// component at a time (tools/error_budget.py): NMTGAN_SPLIT_ABLATE is a bit mask - 1 projections (qkv, o, cross q / kv /
+// o), 2 feed-forward pair, 4 logits, 8 attention inputs (q, K, V rounded to fp16 as the fp16 caches hold them).  A masked
+// GEMM multiplies only the hi halves of its operands (columns 0 .. K-1 of the [hi | lo | hi] and [hi | hi | lo] images):
+// plain fp16 operands with fp32 accumulation, exactly the fp16 tier's product.  0 (default) = the tier as shipped.
+static int split_ablate() {
+  static const int v = [] { const char* e = getenv("NMTGAN_SPLIT_ABLATE"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 // out[s] = (A . Wt^T + b) with up to 3 column segments
 static int dense(int op, const void* A, int64_t lda, int M, int K, int N, const nmtgan_dense& w, int n_seg,
                  int seg_width, void* const* outs, const int64_t* ldos, const int* out_f32, const float* scales,
@@ -51,6 +61,8 @@ static int dense(int op, const void* A, int64_t lda, int M, int K, int N, const 
     if (!presplit) NMTGAN_TRY(split_operand(A, lda, M, K, st));
     a.op_dtype = NMTGAN_F16; a.A = presplit ? presplit : g_split_buf; a.lda = 3 * (int64_t)K; a.K = 3 * K;
     for (int s = 0; s < n_seg; ++s) a.out_f32[s] = out_f32[s] == 2 ? 2 : 1;    // 2: the consumer's operand image
+    const int role = prof::g_hint == prof::GEMM_FFN ? 2 : (prof::g_hint == prof::GEMM_LOGITS ? 4 : 1);
+    if (split_ablate() & role) { a.K = K; a.ldw = 3 * (int64_t)K; }            // hi halves only (error budget)
   }
   return launch_gemm(&a, st);
 }
@@ -144,14 +156,19 @@ static int encode(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_
     int f32[3] = {0, 0, 0};                       // q in op dtype like K/V (the attention kernels take it as such)
     float sc[3] = {qscale, 1.f, 1.f};
     NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st));
+    if (g->gemm_split && g_split_buf && (split_ablate() & 8))
+      for (int s = 0; s < 3; ++s) NMTGAN_TRY(launch_round_f16((float*)outs[s], (int64_t)M * d, st));
     nmtgan_attn_args t{};
     t.q = a.q; t.q_op_dtype = 1; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
     t.k1 = kbuf; t.v1 = vbuf; t.len1 = Ls; t.rows_per_blk = Ls; t.causal = 0; t.mask1 = x_pad; t.out = a.ao;
     NMTGAN_TRY(launch_attn_rows(&t, st));
     NMTGAN_TRY(dense1(op, a.ao, d, M, d, d, b.o, a.yf, d, 1, 1.f, 0, st));
     NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln0, M, a.xo, nullptr, st));
-    NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
-    NMTGAN_TRY(dense1(op, a.h, 4 * d, M, 4 * d, d, b.ffn2, a.yf, d, 1, 1.f, 0, st));
+    {
+      prof::Hint ph(prof::GEMM_FFN);
+      NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
+      NMTGAN_TRY(dense1(op, a.h, 4 * d, M, 4 * d, d, b.ffn2, a.yf, d, 1, 1.f, 0, st));
+    }
     NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln1, M, a.xo, l == g->n_blocks - 1 ? x_pad : nullptr, st));   // model.py:542
   }
   return 0;
@@ -166,6 +183,8 @@ static int cross_kv(const nmtgan_generator* g, const void* enc_op, int M, void* 
     int f32[2] = {0, 0};
     float sc[2] = {1.f, 1.f};
     NMTGAN_TRY(dense(op, enc_op, d, M, d, 2 * d, g->dec[l].ckv, 2, d, outs, ld, f32, sc, 0, st));
+    if (g->gemm_split && g_split_buf && (split_ablate() & 8))
+      for (int s = 0; s < 2; ++s) NMTGAN_TRY(launch_round_f16((float*)outs[s], (int64_t)M * d, st));
   }
   return 0;
 }
@@ -206,6 +225,8 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       int f32[3] = {0, 0, 0};
       float sc[3] = {qscale, 1.f, 1.f};
       NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st, img));
+      if (img && (split_ablate() & 8))
+        for (int s = 0; s < 3; ++s) NMTGAN_TRY(launch_round_f16((float*)outs[s], (int64_t)M * d, st));
     }
     if (c.group_R > 0) {
       // shared prefix keys once per group on MFMA -> running (o, m, l); private suffix per row after
@@ -242,6 +263,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
     }
     NMTGAN_TRY(dense_add_ln(g, a.ao, d, M, d, b.o, b.ln0, a.xf, a.yf, a.xo, st, img, img));
     NMTGAN_TRY(dense1(op, a.xo, d, M, d, d, b.cq, a.q, d, 0, qscale, 0, st, img));
+    if (img && (split_ablate() & 8)) NMTGAN_TRY(launch_round_f16(a.q, (int64_t)M * d, st));
     if (c.group_R > 0) {
       nmtgan_attn_group_args ga{};
       ga.q = a.q; ga.q_bf16 = 1; ga.kv_dtype = op; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
