@@ -193,7 +193,9 @@ __device__ __forceinline__ void store_split3(f16_t* img, int64_t K, const float 
   float hi[N], lo[N];
 #pragma unroll
   for (int e = 0; e < N; ++e) {
-    hi[e] = (float)(f16_t)v[e];
+    // hi is clamped to the fp16 range, so a value up to twice that range still splits exactly instead of turning
+    // into inf - inf
+    hi[e] = (float)(f16_t)fminf(fmaxf(v[e], -65504.f), 65504.f);
     lo[e] = v[e] - hi[e];
   }
   VecIO<f16_t, N>::store(img, hi);

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* A, int64_t lda
   unsigned hi[4], lo[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const f16_t h0 = (f16_t)v[2 * e], h1 = (f16_t)v[2 * e + 1];
+    const f16_t h0 = (f16_t)fminf(fmaxf(v[2 * e], -65504.f), 65504.f);       // clamped: see store_split3
+    const f16_t h1 = (f16_t)fminf(fmaxf(v[2 * e + 1], -65504.f), 65504.f);
     const f16x2_t h = {h0, h1};
     const f16x2_t l = {(f16_t)(v[2 * e] - (float)h0), (f16_t)(v[2 * e + 1] - (float)h1)};
     hi[e] = __builtin_bit_cast(unsigned, h);

@@ -235,6 +235,15 @@ def test_split_precision_gemm(cuda, M, N, K):
     plain = float(((hi.double() @ W.half().double().T) - ref).abs().max() / ref.abs().max())
     print("split-precision GEMM rel err %.3g (plain fp16 operands %.3g)" % (err, plain))
     assert err < 3e-6, err
+    # values beyond the fp16 range: hi is clamped to +-65504 and lo carries the rest (exact up to twice the range)
+    big = torch.tensor([[1.0e5, -7.0e4, 65504.0, -131000.0, 3.0, 0.0, -65520.0, 1.25e5]], device=cuda)
+    img = torch.empty(1, 24, device=cuda, dtype=torch.float16)
+    L.check(L.lib.nmtgan_split3(big.data_ptr(), 8, 1, 8, img.data_ptr(), L.stream_ptr()), "split3")
+    torch.cuda.synchronize()
+    assert torch.isfinite(img.float()).all()
+    assert torch.equal(img[:, :8], img[:, 16:])
+    back = img[:, :8].float() + img[:, 8:16].float()
+    assert ((back - big).abs() <= big.abs() * 2.0 ** -11).all(), (back, big)
 
 
 def _attn_ref(q, keys, vals, heads):
