@@ -40,9 +40,9 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     """Every hand-mirrored ctypes struct has the size the C compiler gives the struct of include/nmtgan.h,
     and its last field sits at the same offset (gcc on the header itself)."""
     from nmt_gan_amd import _lib
-    pairs = {"nmtgan_gemm_args": (_lib.GemmArgs, "ln_out"), "nmtgan_embed_args": (_lib.EmbedArgs, "op_dtype"),
-             "nmtgan_addln_args": (_lib.AddLnArgs, "zero_row"), "nmtgan_attn_args": (_lib.AttnArgs, "q_op_dtype"),
-             "nmtgan_attn_group_args": (_lib.AttnGroupArgs, "kv_dtype"), "nmtgan_sample_args": (_lib.SampleArgs, "out"),
+    pairs = {"nmtgan_gemm_args": (_lib.GemmArgs, "ln_out"), "nmtgan_embed_args": (_lib.EmbedArgs, "out_split"),
+             "nmtgan_addln_args": (_lib.AddLnArgs, "out_split"), "nmtgan_attn_args": (_lib.AttnArgs, "out_split"),
+             "nmtgan_attn_group_args": (_lib.AttnGroupArgs, "out_split"), "nmtgan_sample_args": (_lib.SampleArgs, "out"),
              "nmtgan_generator": (_lib.Generator, "gemm_split"), "nmtgan_discriminator": (_lib.Discriminator, "head_b"),
              "nmtgan_reward_plan": (_lib.RewardPlan, "conv_bucket_taps"),
              "nmtgan_disc_tower_params": (_lib.DiscTowerParams, "hw_tr"), "nmtgan_disc_params": (_lib.DiscParams, "head_b")}
