@@ -210,7 +210,7 @@ T = 10
 gcfg, dcfg = tiny_cfgs(d=128, heads=4, T=T)
 Wg, Wd = O.init_generator_weights(gcfg, 0), disc_weights(dcfg, 1)
 results = {}
-for precision in ("fp32", "fp16"):
+for precision in ("fp32", "fp16", "fp16x3"):
     m, disc = make_gpu_pair(gcfg, dcfg, Wg, Wd, precision, T)
     for name, B, R in (("sentence-sharded", 5, 3), ("roll-sharded", 1, 4)):
         x, y = O.synthetic_batch(B, T, gcfg.src_vocab_size, gcfg.dst_vocab_size, seed=7 + B, eos_rows=(0,) if B == 1 else (1,))
