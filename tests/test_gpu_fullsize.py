@@ -1,4 +1,4 @@
-"""Full-size (BASELINE.json configs[1] = C2: d512 N6 h8, B64 R16 T50 V32000, fp16 tier) checks of the
+"""Full-size (BASELINE.json configs[1] = C2: d512 N6 h8, B64 R16 T50 V32000; fp16 and split-precision tiers) checks of the
 rollout-reward path through properties that do not need the oracle to replay 1.25 M sampled tokens
 (the oracle cannot replay them in seconds): determinism, prefix preservation, shard invariance (uniforms are addressed by
 global sentence id), range and masking of the rewards, the reward tail recomputed on the host in the
@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 D, BLOCKS, HEADS, V, E, T, R, B = 512, 6, 8, 32000, 512, 50, 16, 64
 
 
-@pytest.fixture(scope="module")
-def c2(cuda):
+@pytest.fixture(scope="module", params=["fp16", "fp16x3"])
+def c2(cuda, request):
     import nmt_gan_amd as N
     from nmt_gan_amd import synthetic
     from nmt_gan_amd.utils import AttrDict as Cfg
@@ -25,12 +25,12 @@ def c2(cuda):
     widths, nfs = synthetic.disc_filters(T)
     mcfg = Cfg(hidden_units=D, num_blocks=BLOCKS, num_heads=HEADS, src_vocab_size=V, dst_vocab_size=V,
                scale_embedding=True, residual_dropout_rate=0.0, train=Cfg(shared_embedding=False))
-    model = N.Model(mcfg, precision="fp16")
+    model = N.Model(mcfg, precision=request.param)
     model.build_train_model()
     model.build_generate(T)
     model.build_rollout_generate(T)
     model.init_and_restore(weights=Wg)
-    disc = N.DisCNN(None, T, 2, V, B, E, widths, nfs, vocab_size_s=V, precision="fp16")
+    disc = N.DisCNN(None, T, 2, V, B, E, widths, nfs, vocab_size_s=V, precision=request.param)
     disc.load_weights(Wd)
     x, y = synthetic.synthetic_batch(B, T, V, V, seed=1234)
     y[3, 20] = O.EOS_ID                                   # ragged: one early </S>, one very short sample
