@@ -95,7 +95,8 @@ PROFILE_TAG = {"fp16": "r2_c2_fp16", "bf16": "r1_c2_bf16", "fp16x3": "r2_c2_fp16
 TRAFFIC_KERNELS = {
     "gemm_conv": r"gemm_\w+_kernel<(unsigned short|_Float16), 1[,>]",
     "gemm_logits": r"gemm_\w+_kernel<(unsigned short|_Float16), (2|100)[,>]",     # 2 in the bf16 summary, made by an earlier build
-    "attn_self_private": r"attn_rows_(bf16|16)_kernel",
+    # (the split-precision tier's fp32 row kernel also serves its 24 encoder / prefill launches, 8 % of the launches)
+    "attn_self_private": r"attn_rows_(bf16|16)_kernel|attn_rows_kernel<float",
     "add_layernorm": r"addln_kernel",
     "sampler_rows": r"sample_kernel",
 }
