@@ -1391,7 +1391,8 @@ static int tile_override() {        // NMTGAN_GEMM_TILE=128|256|0(generic) for e
 // MFMA + LDS + DMA load), so the 256x256 kernel - fewer LDS and L2 bytes per flop - wins whenever its
 // larger tiles are not wasted on padding and the k-loop is long enough to amortise its epilogue.
 // Measured padded rates (bf16, random operands): ~1250 TFLOP/s for 256x256, ~1080 for 256x128.
-static int p8_mode() {              // NMTGAN_GEMM_P8=0 never, 1 heuristic (default), 2 always when legal
+static int p8_mode() {              // NMTGAN_GEMM_P8=0 never, 1 heuristic (default), 2 always when legal, 3 the tile-count
+                                    // thresholds also for the LINEAR epilogue (the rule before the rounds model)
   static const int v = [] { const char* e = getenv("NMTGAN_GEMM_P8"); return e ? atoi(e) : 1; }();
   return v;
 }
@@ -1404,6 +1405,20 @@ static bool prefer_p8(int64_t M, int N, int nkt) {
   if (nkt < 16 && N < 2048) return false;        // K = 512 projections: the 256x128 kernel's store overlap wins
   const double t_p8 = (double)((N + 255) / 256 * 256) / 1250.0, t_pipe = (double)((N + 127) / 128 * 128) / 1080.0;
   return t_p8 < t_pipe;
+}
+// LINEAR epilogue, 16-bit operands: the two persistent kernels priced as (rounds of tiles over the CUs) x (time of one
+// tile = fixed part + part per 128-byte k-tile), microseconds fitted to sweeps over the row counts of the rollout steps
+// (tools/sweep_p8.py; 256x128: 5.7 + 0.854 nkt, 256x256: 13.3 + 1.21 nkt).  The 256x256 tile does twice the work in 1.4x
+// the k-loop time but pays 2.3x the fixed part, and which kernel fills its last round better changes every few
+// thousand rows; the model picks the faster kernel on every sampled point of qkv / cq / ffn1 and all but the largest of ffn2.
+static bool prefer_p8_linear(int64_t M, int N, int nkt) {
+  const int mode = p8_mode();
+  if (mode == 0 || nkt < 4) return false;
+  if (mode == 2) return true;
+  const int64_t cus = persistent_grid(1 << 30);
+  const int64_t rt = (M + 255) / 256;
+  const int64_t rounds_pipe = (rt * ((N + 127) / 128) + cus - 1) / cus, rounds_p8 = (rt * ((N + 255) / 256) + cus - 1) / cus;
+  return (double)rounds_p8 * (13.3 + 1.21 * nkt) < (double)rounds_pipe * (5.7 + 0.854 * nkt);
 }
 template <typename OpT, int EPI>
 static int dispatch(const GemmParams& p, hipStream_t st) {
@@ -1431,7 +1446,8 @@ static int dispatch(const GemmParams& p, hipStream_t st) {
       return launch_pipe<OpT, EPI>(b, st);
     }
   }
-  if (pipe_ok && prefer_p8(p.M, p.N, nkt)) return launch_p8<OpT, EPI>(p, st);
+  const bool modelled = EPI == NMTGAN_EPI_LINEAR && sizeof(OpT) == 2 && tiles256 >= 16 && p8_mode() != 3;
+  if (pipe_ok && (modelled ? prefer_p8_linear(p.M, p.N, nkt) : prefer_p8(p.M, p.N, nkt))) return launch_p8<OpT, EPI>(p, st);
   static const int pipe_min_tiles = [] { const char* e = getenv("NMTGAN_PIPE_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
   if (pipe_ok && (ov == 3 || (ov < 0 && tiles256 >= pipe_min_tiles))) return launch_pipe<OpT, EPI>(p, st);
   if (ov == 256) return launch_glds<OpT, EPI, 256, 128>(p, st);
