@@ -152,5 +152,9 @@ if __name__ == "__main__":
             for K in (512, 2048):
                 run_addln(M, K)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "addln-sweep":       # the row counts of the rollout steps, K = 512
+        for M in range(2048, 50177, 2048):
+            run_addln(M, 512)
+        sys.exit(0)
     for s in SHAPES:
         run(*s)
