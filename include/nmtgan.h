@@ -301,6 +301,18 @@ typedef struct {                       /* DisCNN inference weights */
   nmtgan_disc_tower tgt, src;
   const float* head_w;                 /* [2][2*Fp] fp32: class-major, [tgt Fp | src Fp] */
   const float* head_b;                 /* [2] */
+  int gemm_split;                      /* != 0 (needs op_dtype NMTGAN_F16): the split-precision form of the scoring path -
+                                          cnn_discriminator.py:440-522 computes in fp32, and with |score| ~ 100 a 16-bit
+                                          operand rounding moves P(real) by percents - with every product as ONE fp16 MFMA
+                                          GEMM over hi/lo operand splits, interleaved PER TOKEN / PER TAP so that a conv
+                                          window stays one contiguous slice of the sentence image:
+                                          emb      fp16 [V][3E]        row  = [e_hi | e_lo | e_hi]
+                                          conv_w   fp16 Wt[n_w][w][3E] tap  = [W_hi | W_hi | W_lo]
+                                          hw_*     fp16 Wt[Fp][3Fp]         = [W_hi | W_hi | W_lo]   (the pooled features
+                                          are split on the fly, nmtgan_split3)
+                                          with x_hi = fp16(x), x_lo = fp16(x - x_hi); dim_word stays E.  Accumulation,
+                                          BatchNorm, max-pool, gate and head are fp32 as in every tier.  Scoring only
+                                          (nmtgan_disc_train_grads refuses it). */
 } nmtgan_discriminator;
 
 /* ------------------------------------------------------------------------------------------

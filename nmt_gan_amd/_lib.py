@@ -95,7 +95,8 @@ class DiscTower(C.Structure):
 class Discriminator(C.Structure):
     _fields_ = [("op_dtype", i32), ("max_len", i32), ("dim_word", i32), ("vocab", i32), ("vocab_s", i32),
                 ("n_widths", i32), ("widths", i32 * MAX_WIDTHS), ("n_filters", i32 * MAX_WIDTHS),
-                ("F", i32), ("Fp", i32), ("tgt", DiscTower), ("src", DiscTower), ("head_w", vp), ("head_b", vp)]
+                ("F", i32), ("Fp", i32), ("tgt", DiscTower), ("src", DiscTower), ("head_w", vp), ("head_b", vp),
+                ("gemm_split", i32)]
 
 
 class DiscTowerParams(C.Structure):
@@ -208,6 +209,25 @@ def split3_weights(w):
     hi = w.to(torch.float16)
     lo = (w - hi.to(torch.float32)).to(torch.float16)
     return torch.cat([hi, hi, lo], dim=1).contiguous()
+
+
+def split3_acts(a):
+    """fp32 [M, K] (torch) -> fp16 [M, 3K] = [A_hi | A_lo | A_hi]: the activation side of a split-precision product
+    (what nmtgan_split3 writes); used for tables that are gathered into a GEMM operand (the discriminator's embeddings)."""
+    import torch
+    a = a.to(torch.float32)
+    hi = a.to(torch.float16)
+    lo = (a - hi.to(torch.float32)).to(torch.float16)
+    return torch.cat([hi, lo, hi], dim=1).contiguous()
+
+
+def split3_conv_weights(wt, taps):
+    """Conv filter bank Wt[n, taps*E] fp32 (torch) -> fp16 [n, taps*3E], every tap as [W_hi | W_hi | W_lo]: the weight
+    side of nmtgan_discriminator.gemm_split, interleaved per tap so that it matches a sentence image whose tokens are
+    [e_hi | e_lo | e_hi] rows."""
+    n, k = wt.shape
+    e = k // taps
+    return split3_weights(wt.reshape(n * taps, e)).reshape(n, taps * 3 * e).contiguous()
 
 
 def check(rc: int, what: str = "nmtgan"):

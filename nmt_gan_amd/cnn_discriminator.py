@@ -55,12 +55,16 @@ class DisCNN(object):
         self.num_filters_total = int(sum(self.num_filters))
         self.scope = scope
         self.saveto = saveto
-        if precision == _lib.SPLIT_PRECISION:      # the generator's split-precision tier pairs with an fp16 discriminator
-            precision = "fp16"
+        # 'fp16x3': the split-precision scoring form (nmtgan_discriminator.gemm_split) - every product of the two towers
+        # as one fp16 MFMA GEMM over hi/lo operand splits, fp32-class P(real) at three times the fp16 conv cost.  The
+        # reference scores in fp32 (cnn_discriminator.py:440-522) and its 2-way score reaches |s| ~ 100, where plain
+        # 16-bit operands move P(real) by percents; this is the tier that keeps rewards within 1e-3 of the fp32 path.
         self.precision = precision
+        self.split = precision == _lib.SPLIT_PRECISION
+        self.split_ablate = {}     # error-budget runs only: stages packed WITHOUT their lo halves (see load_weights)
         self.device = torch.device(device)
         self.chunk_rows = int(chunk_rows)
-        self._tdtype, self._op = _op_torch_dtype(precision)
+        self._tdtype, self._op = _op_torch_dtype("fp16" if self.split else precision)
         if len(self.filter_sizes) != len(self.num_filters) or len(self.filter_sizes) > _lib.MAX_WIDTHS:
             raise ValueError("filter_sizes/num_filters mismatch or more than %d widths" % _lib.MAX_WIDTHS)
         if max(self.filter_sizes) > self.max_len:
@@ -99,8 +103,50 @@ class DisCNN(object):
             keep.append(t)
             return t
 
+        # split form: tables as [hi | lo | hi] rows, filters per tap and highway matrices as [hi | hi | lo].  An
+        # ablated stage (error budget: split_ablate = {"emb": True, "conv": [widths], "pooled": True, "hw": True})
+        # loses its lo halves, which leaves exactly the fp16 tier's rounding of that one operand: "emb" the sentence
+        # image, "conv" the filters of the listed widths, "hw" the highway matrices, "pooled" the pooled features
+        # (their lo block meets W_hi in the middle third of the highway image, so that third is zeroed)
+        abl = self.split_ablate if self.split else {}
+
+        def zero_third(t, third, period):          # zero one third of every `period`-wide group of columns
+            v = t.view(t.shape[0], -1, 3, period // 3)
+            v[:, :, third, :] = 0
+            return t
+
+        def pack_emb(emb):
+            if not self.split:
+                return dv(emb, td)
+            t = _lib.split3_acts(torch.as_tensor(emb).to(dev))
+            if abl.get("emb"):
+                zero_third(t, 1, 3 * E)
+            keep.append(t)
+            return t
+
+        def pack_conv(WcT, w):                     # Wt[n][w*E]
+            if not self.split:
+                return dv(WcT, td)
+            t = _lib.split3_conv_weights(torch.as_tensor(np.ascontiguousarray(WcT)).to(dev), w)
+            if w in (abl.get("conv") or ()):
+                zero_third(t, 2, 3 * E)
+            keep.append(t)
+            return t
+
+        def pack_hw(Wh):                           # Wt[Fp][Fp]
+            if not self.split:
+                return dv(Wh, td)
+            t = _lib.split3_weights(torch.as_tensor(Wh).to(dev))
+            if abl.get("hw"):
+                zero_third(t, 2, 3 * Fp)
+            if abl.get("pooled"):
+                zero_third(t, 1, 3 * Fp)
+            keep.append(t)
+            return t
+
         c = _lib.Discriminator()
         c.op_dtype = self._op
+        c.gemm_split = 1 if self.split else 0
         c.max_len, c.dim_word, c.vocab, c.vocab_s = self.max_len, E, self.vocab_size, self.vocab_size_s
         c.n_widths = len(self.filter_sizes)
         for i, (w, n) in enumerate(zip(self.filter_sizes, self.num_filters)):
@@ -109,7 +155,7 @@ class DisCNN(object):
 
         def tower(ct, emb_name, conv_fmt, out_name, tr_name):
             emb = np.asarray(W[s + emb_name], np.float32)
-            ct.emb = ptr(dv(emb, td))
+            ct.emb = ptr(pack_emb(emb))
             for i, (w, n) in enumerate(zip(self.filter_sizes, self.num_filters)):
                 p = s + conv_fmt % w + "/"
                 Wc = np.asarray(W[p + "self_model/W"], np.float32).reshape(w * E, n)
@@ -119,13 +165,13 @@ class DisCNN(object):
                 mean, var = np.asarray(W[bn + "moving_mean"], np.float32), np.asarray(W[bn + "moving_variance"], np.float32)
                 inv = (np.float32(1.0) / np.sqrt(var + np.float32(BN_EPS))).astype(np.float32) * gamma
                 shift = (b * inv + (beta - mean * inv)).astype(np.float32)
-                ct.conv_w[i] = ptr(dv(Wc.T, td))
+                ct.conv_w[i] = ptr(pack_conv(Wc.T, w))
                 ct.conv_scale[i] = ptr(dv(inv, torch.float32))
                 ct.conv_shift[i] = ptr(dv(shift, torch.float32))
             for field, name in (("hw_out", out_name), ("hw_tr", tr_name)):
                 Wh = np.zeros((Fp, Fp), np.float32)
                 Wh[:F, :F] = np.asarray(W[s + name + "/weights"], np.float32).T       # Wt[out][in]
-                setattr(ct, field, ptr(dv(Wh, td)))
+                setattr(ct, field, ptr(pack_hw(Wh)))
 
         tower(c.tgt, "model_self/embeddingtable", "conv_maxpool-%d", "output_lin_0", "transform_lin_0")
         tower(c.src, "model_self/embeddingtable_s", "conv_s_maxpool-%d", "output_s_lin_0", "transform_s_lin_0")
@@ -203,20 +249,25 @@ class DisCNN(object):
         ms = torch.ones(off, dtype=torch.float32, device=dev)
         # operand copies: `opc` in the model's own op dtype (scoring); an fp16 model trains on a bf16 copy (the
         # backward pass keeps gradient-sized values in the operand type, which underflow in fp16)
-        opc = master.to(self._tdtype) if self.precision != "fp32" else None
-        opc_train = master.to(torch.bfloat16) if self.precision == "fp16" else opc
+        # the split form scores from a flat fp16 buffer with every table / filter bank / highway matrix in its split
+        # layout at three times its master offset (refreshed from the master after each update) and trains on bf16 too
+        half = self.precision in ("fp16", _lib.SPLIT_PRECISION)
+        opc = master.to(self._tdtype) if self.precision not in ("fp32", _lib.SPLIT_PRECISION) else None
+        opc_train = master.to(torch.bfloat16) if half else opc
+        spl = torch.zeros(3 * off, dtype=torch.float16, device=dev) if self.split else None
         stats = {t: (torch.from_numpy(m.copy()).to(dev), torch.from_numpy(v.copy()).to(dev)) for t, (m, v) in moving.items()}
         fold = {t: (torch.zeros(F, dtype=torch.float32, device=dev), torch.zeros(F, dtype=torch.float32, device=dev))
                 for t in moving}
         pc, gc = _lib.DiscParams(), _lib.DiscParams()
         index, col_off = {}, np.concatenate([[0], np.cumsum(self.num_filters)]).astype(int)
 
-        def build(opbuf, opcode):
+        def build(opbuf, opcode, split=False):
             c = _lib.Discriminator.from_buffer_copy(self._c)
             c.op_dtype = opcode
+            c.gemm_split = 1 if split else 0
             for key, tf_name, kind, o, a in chunks:
                 mptr = master.data_ptr() + 4 * o
-                optr = (opbuf.data_ptr() + 2 * o) if opbuf is not None else mptr
+                optr = (opbuf.data_ptr() + 2 * o * (3 if split else 1)) if opbuf is not None else mptr
                 if key[0] in ("tgt", "src"):
                     ct = getattr(c, key[0])
                     if key[1] == "emb":
@@ -255,17 +306,38 @@ class DisCNN(object):
         for t in ("tgt", "src"):
             pt = getattr(pc, t)
             pt.moving_mean, pt.moving_var = stats[t][0].data_ptr(), stats[t][1].data_ptr()
-        c = build(opc, self._op)
-        c_train = build(opc_train, _lib.NMTGAN_BF16) if self.precision == "fp16" else c
-        self._keep = [master, grad, ms, stats, fold] + [t for t in (opc, opc_train) if t is not None]
+        c = build(spl, self._op, split=True) if self.split else build(opc, self._op)
+        c_train = build(opc_train, _lib.NMTGAN_BF16) if half else c
+        self._keep = [master, grad, ms, stats, fold] + [t for t in (opc, opc_train, spl) if t is not None]
         self._c = c
         self._train = dict(master=master, grad=grad, ms=ms, op=opc, op_train=opc_train, c_train=c_train,
-                           op_train_code=_lib.NMTGAN_BF16 if self.precision == "fp16" else self._op,
+                           op_train_code=_lib.NMTGAN_BF16 if half else self._op, split=spl,
                            pc=pc, gc=gc, index=index, n=off, stats=stats, fold=fold,
                            steps=0, loss=torch.zeros(1, dtype=torch.float32, device=dev),
                            acc=torch.zeros(1, dtype=torch.float32, device=dev))
         self._fold_bn()
+        self._refresh_split()
         return self._train
+
+    def _refresh_split(self):
+        """Split form: rebuild the scoring copy (tables [hi | lo | hi], filters per tap and highway matrices
+        [hi | hi | lo]) from the fp32 master."""
+        tr = self._train
+        if tr is None or tr.get("split") is None:
+            return
+        master, spl, E, Fp = tr["master"], tr["split"], self.dim_word, self.Fp
+        for key, (tf_name, kind, o, n) in tr["index"].items():
+            src = master[o:o + n]
+            if kind == "tab":
+                img = _lib.split3_acts(src.view(-1, E))
+            elif kind == "conv":
+                w = key[2]
+                img = _lib.split3_conv_weights(src.view(-1, w * E), w)
+            elif kind == "hw":
+                img = _lib.split3_weights(src.view(Fp, Fp))
+            else:
+                continue
+            spl[3 * o:3 * o + 3 * n].copy_(img.reshape(-1))
 
     def _fold_bn(self):
         tr, F = self._train, self.num_filters_total
@@ -350,6 +422,7 @@ class DisCNN(object):
             check(lib.nmtgan_clip_values(ptr(tr["master"]), tr["n"], float("-inf"), float("inf"), ptr(tr["op"]), self._op, st),
                   "nmtgan_clip_values")
         self._fold_bn()
+        self._refresh_split()
         torch.cuda.synchronize(dev)
         out = (float(la[0].item()), float(la[1].item()))
         return out + (grads,) if return_grads else out

@@ -16,22 +16,15 @@ namespace nmtgan {
 
 static inline char* at(const void* base, int64_t elems, int es) { return (char*)base + elems * es; }
 
-// Split-precision GEMM form of the calling thread (nmtgan_generator.gemm_split): scratch for the split A operand.
-// Set by the generator pipelines around their launches; everything they enqueue goes to ONE stream, in order, so one
-// buffer serves every GEMM.
-static thread_local void* g_split_buf = nullptr;
-static thread_local size_t g_split_bytes = 0;
-struct SplitScope {
-  SplitScope(const nmtgan_generator* g, void* buf, size_t bytes) {
-    g_split_buf = g->gemm_split ? buf : nullptr;
-    g_split_bytes = g->gemm_split ? bytes : 0;
-  }
-  ~SplitScope() { g_split_buf = nullptr; g_split_bytes = 0; }
-};
-// A [M][K] fp32 -> the thread's scratch as fp16 [M][3K] = [hi | lo | hi]
-static int split_operand(const void* A, int64_t lda, int M, int K, hipStream_t st) {
-  NMTGAN_REQUIRE((size_t)M * 3 * K * sizeof(f16_t) <= g_split_bytes, "split GEMM: scratch too small for %d x %d", M, K);
-  return launch_split3((const float*)A, lda, M, K, g_split_buf, st);
+// Split-precision GEMM form (nmtgan_generator.gemm_split): the scratch that receives the [hi | lo | hi] image of a GEMM
+// input whose producer did not write it.  A pipeline passes its own context to the GEMMs of the GENERATOR only - the
+// discriminator's launches never see it - and everything that uses one context is enqueued on ONE stream, in order,
+// so one buffer serves every GEMM.  nullptr = plain GEMM in the model's op dtype.
+struct SplitCtx { void* buf; size_t bytes; };
+// A [M][K] fp32 -> the context's scratch as fp16 [M][3K] = [hi | lo | hi]
+static int split_operand(const SplitCtx* sp, const void* A, int64_t lda, int M, int K, hipStream_t st) {
+  NMTGAN_REQUIRE((size_t)M * 3 * K * sizeof(f16_t) <= sp->bytes, "split GEMM: scratch too small for %d x %d", M, K);
+  return launch_split3((const float*)A, lda, M, K, sp->buf, st);
 }
 
 // Error budget of the 16-bit tiers, measured from the split-precision tier by taking the precision away from ONE
@@ -45,9 +38,9 @@ static int split_ablate() {
 }
 
 // out[s] = (A . Wt^T + b) with up to 3 column segments
-static int dense(int op, const void* A, int64_t lda, int M, int K, int N, const nmtgan_dense& w, int n_seg,
-                 int seg_width, void* const* outs, const int64_t* ldos, const int* out_f32, const float* scales,
-                 int relu, hipStream_t st, const void* presplit = nullptr) {
+static int dense(int op, const SplitCtx* sp, const void* A, int64_t lda, int M, int K, int N, const nmtgan_dense& w,
+                 int n_seg, int seg_width, void* const* outs, const int64_t* ldos, const int* out_f32,
+                 const float* scales, int relu, hipStream_t st, const void* presplit = nullptr) {
   nmtgan_gemm_args a{};
   a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
   a.A = A; a.Wt = w.w; a.M = M; a.N = N; a.K = K; a.lda = lda; a.a_group = 0;
@@ -55,24 +48,26 @@ static int dense(int op, const void* A, int64_t lda, int M, int K, int N, const 
   for (int s = 0; s < n_seg; ++s) {
     a.out[s] = outs[s]; a.ldo[s] = ldos[s]; a.out_f32[s] = out_f32[s]; a.seg_scale[s] = scales ? scales[s] : 1.f;
   }
-  if (g_split_buf && op == NMTGAN_F32) {           // w.w is fp16 [N][3K] = [hi | hi | lo]; outputs stay fp32
+  if (sp) {                                        // w.w is fp16 [N][3K] = [hi | hi | lo]; outputs stay fp32
+    NMTGAN_REQUIRE(op == NMTGAN_F32, "split GEMM: the model must be packed with fp32 storage");
     // presplit: the producer of A already wrote its [hi | lo | hi] image (add_layernorm, attention, the first
     // feed-forward layer); else one pass over A makes it in the thread's scratch
-    if (!presplit) NMTGAN_TRY(split_operand(A, lda, M, K, st));
-    a.op_dtype = NMTGAN_F16; a.A = presplit ? presplit : g_split_buf; a.lda = 3 * (int64_t)K; a.K = 3 * K;
+    if (!presplit) NMTGAN_TRY(split_operand(sp, A, lda, M, K, st));
+    a.op_dtype = NMTGAN_F16; a.A = presplit ? presplit : sp->buf; a.lda = 3 * (int64_t)K; a.K = 3 * K;
     for (int s = 0; s < n_seg; ++s) a.out_f32[s] = out_f32[s] == 2 ? 2 : 1;    // 2: the consumer's operand image
     const int role = prof::g_hint == prof::GEMM_FFN ? 2 : (prof::g_hint == prof::GEMM_LOGITS ? 4 : 1);
     if (split_ablate() & role) { a.K = K; a.ldw = 3 * (int64_t)K; }            // hi halves only (error budget)
   }
   return launch_gemm(&a, st);
 }
-static int dense1(int op, const void* A, int64_t lda, int M, int K, int N, const nmtgan_dense& w, void* out,
-                  int64_t ldo, int out_is_f32, float scale, int relu, hipStream_t st, const void* presplit = nullptr) {
+static int dense1(int op, const SplitCtx* sp, const void* A, int64_t lda, int M, int K, int N, const nmtgan_dense& w,
+                  void* out, int64_t ldo, int out_is_f32, float scale, int relu, hipStream_t st,
+                  const void* presplit = nullptr) {
   void* outs[1] = {out};
   int64_t ld[1] = {ldo};
   int f[1] = {out_is_f32};
   float sc[1] = {scale};
-  return dense(op, A, lda, M, K, N, w, 1, N, outs, ld, f, sc, relu, st, presplit);
+  return dense(op, sp, A, lda, M, K, N, w, 1, N, outs, ld, f, sc, relu, st, presplit);
 }
 
 static int add_ln(const nmtgan_generator* g, float* xf, const float* yf, const nmtgan_ln& ln, int M, void* xo,
@@ -89,8 +84,8 @@ static int add_ln(const nmtgan_generator* g, float* xf, const float* yf, const n
 // bound by the matrix cores and runs faster on the 256x256 kernel even with the extra round trip of yf;
 // NMTGAN_FUSE_LN=2 fuses it too, 0 fuses nothing).  The split-K pipelines (B-row greedy decode) keep the two-kernel
 // form: their projections are cut into k-slices to fill the CUs.
-static int dense_add_ln(const nmtgan_generator* g, const void* A, int64_t lda, int M, int K, const nmtgan_dense& w,
-                        const nmtgan_ln& ln, float* xf, float* yf, void* xo, hipStream_t st,
+static int dense_add_ln(const nmtgan_generator* g, const SplitCtx* sp, const void* A, int64_t lda, int M, int K,
+                        const nmtgan_dense& w, const nmtgan_ln& ln, float* xf, float* yf, void* xo, hipStream_t st,
                         const void* a_img = nullptr, void* x_img = nullptr) {
   static const int fuse = [] { const char* e = getenv("NMTGAN_FUSE_LN"); return e ? atoi(e) : 1; }();
   if (fuse > 0 && (K <= g->d || fuse > 1) && !gemm_splitk_active() && gemm_addln_supported(g->op_dtype, g->d, K)) {
@@ -101,7 +96,7 @@ static int dense_add_ln(const nmtgan_generator* g, const void* A, int64_t lda, i
     return launch_gemm(&a, st);
   }
   // split-precision form: a_img = A's operand image written by its producer, x_img = where to leave the image of x
-  NMTGAN_TRY(dense1(g->op_dtype, A, lda, M, K, g->d, w, yf, g->d, 1, 1.f, 0, st, a_img));
+  NMTGAN_TRY(dense1(g->op_dtype, sp, A, lda, M, K, g->d, w, yf, g->d, 1, 1.f, 0, st, a_img));
   prof::Hint own_class(-1);                      // the add_layernorm launch is timed under its own class
   return add_ln(g, xf, yf, ln, M, xo, nullptr, st, x_img);
 }
@@ -125,6 +120,8 @@ struct Act {
   void* img;                                  // split-precision tier: [hi | lo | hi] image (rows x 3 d fp16) of the
                                               // current d-wide GEMM operand (x after embed / LayerNorm, or the
                                               // attention output), written by the kernel that produces it
+  SplitCtx sc; bool use_split;                // the generator's split context (sc = {split, split_bytes})
+  const SplitCtx* sp() const { return use_split ? &sc : nullptr; }
 };
 static void carve_act(Arena& ar, int64_t rows, int d, int es, Act& a, bool gemm_split = false) {
   a.xf = ar.get<float>(rows * d);
@@ -136,6 +133,8 @@ static void carve_act(Arena& ar, int64_t rows, int d, int es, Act& a, bool gemm_
   a.split_bytes = gemm_split ? (size_t)rows * 12 * d * sizeof(f16_t) : 0;
   a.split = gemm_split ? ar.take(a.split_bytes) : nullptr;
   a.img = gemm_split ? ar.take((size_t)rows * 3 * d * sizeof(f16_t)) : nullptr;
+  a.sc = SplitCtx{a.split, a.split_bytes};
+  a.use_split = gemm_split;
 }
 
 // ------------------------------------------------------------------------------------------ encoder
@@ -155,19 +154,19 @@ static int encode(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_
     int64_t ld[3] = {d, d, d};
     int f32[3] = {0, 0, 0};                       // q in op dtype like K/V (the attention kernels take it as such)
     float sc[3] = {qscale, 1.f, 1.f};
-    NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st));
-    if (g->gemm_split && g_split_buf && (split_ablate() & 8))
+    NMTGAN_TRY(dense(op, a.sp(), a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st));
+    if (a.sp() && (split_ablate() & 8))
       for (int s = 0; s < 3; ++s) NMTGAN_TRY(launch_round_f16((float*)outs[s], (int64_t)M * d, st));
     nmtgan_attn_args t{};
     t.q = a.q; t.q_op_dtype = 1; t.M = M; t.d = d; t.heads = g->heads; t.kv_dtype = op;
     t.k1 = kbuf; t.v1 = vbuf; t.len1 = Ls; t.rows_per_blk = Ls; t.causal = 0; t.mask1 = x_pad; t.out = a.ao;
     NMTGAN_TRY(launch_attn_rows(&t, st));
-    NMTGAN_TRY(dense1(op, a.ao, d, M, d, d, b.o, a.yf, d, 1, 1.f, 0, st));
+    NMTGAN_TRY(dense1(op, a.sp(), a.ao, d, M, d, d, b.o, a.yf, d, 1, 1.f, 0, st));
     NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln0, M, a.xo, nullptr, st));
     {
       prof::Hint ph(prof::GEMM_FFN);
-      NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
-      NMTGAN_TRY(dense1(op, a.h, 4 * d, M, 4 * d, d, b.ffn2, a.yf, d, 1, 1.f, 0, st));
+      NMTGAN_TRY(dense1(op, a.sp(), a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
+      NMTGAN_TRY(dense1(op, a.sp(), a.h, 4 * d, M, 4 * d, d, b.ffn2, a.yf, d, 1, 1.f, 0, st));
     }
     NMTGAN_TRY(add_ln(g, a.xf, a.yf, b.ln1, M, a.xo, l == g->n_blocks - 1 ? x_pad : nullptr, st));   // model.py:542
   }
@@ -175,15 +174,16 @@ static int encode(const nmtgan_generator* g, const int32_t* x, const uint8_t* x_
 }
 
 // cross-attention K/V of every decoder block from the encoder output (op dtype, [B*Ls][d])
-static int cross_kv(const nmtgan_generator* g, const void* enc_op, int M, void* crossK, void* crossV, hipStream_t st) {
+static int cross_kv(const nmtgan_generator* g, const SplitCtx* sp, const void* enc_op, int M, void* crossK, void* crossV,
+                    hipStream_t st) {
   const int op = g->op_dtype, d = g->d, es = dtype_size(op);
   for (int l = 0; l < g->n_blocks; ++l) {
     void* outs[2] = {at(crossK, (int64_t)l * M * d, es), at(crossV, (int64_t)l * M * d, es)};
     int64_t ld[2] = {d, d};
     int f32[2] = {0, 0};
     float sc[2] = {1.f, 1.f};
-    NMTGAN_TRY(dense(op, enc_op, d, M, d, 2 * d, g->dec[l].ckv, 2, d, outs, ld, f32, sc, 0, st));
-    if (g->gemm_split && g_split_buf && (split_ablate() & 8))
+    NMTGAN_TRY(dense(op, sp, enc_op, d, M, d, 2 * d, g->dec[l].ckv, 2, d, outs, ld, f32, sc, 0, st));
+    if (sp && (split_ablate() & 8))
       for (int s = 0; s < 2; ++s) NMTGAN_TRY(launch_round_f16((float*)outs[s], (int64_t)M * d, st));
   }
   return 0;
@@ -215,7 +215,8 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
   // Split-precision tier: every producer of a GEMM operand writes the operand's fp16 [hi | lo | hi] image itself
   // (the embedding before this pass, add_layernorm, the attention kernels, the first feed-forward layer), so no
   // stand-alone split pass runs between the layers.  a.img holds x's image when this function is entered and left.
-  void* const img = (g->gemm_split && g_split_buf) ? a.img : nullptr;
+  const SplitCtx* const sp = a.sp();
+  void* const img = sp ? a.img : nullptr;
   void* const attn_out = img ? img : a.ao;
   for (int l = 0; l < g->n_blocks; ++l) {
     const nmtgan_dec_block& b = g->dec[l];
@@ -224,7 +225,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       int64_t ld[3] = {d, d, d};
       int f32[3] = {0, 0, 0};
       float sc[3] = {qscale, 1.f, 1.f};
-      NMTGAN_TRY(dense(op, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st, img));
+      NMTGAN_TRY(dense(op, sp, a.xo, d, M, d, 3 * d, b.qkv, 3, d, outs, ld, f32, sc, 0, st, img));
       if (img && (split_ablate() & 8))
         for (int s = 0; s < 3; ++s) NMTGAN_TRY(launch_round_f16((float*)outs[s], (int64_t)M * d, st));
     }
@@ -261,8 +262,8 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       prof::Hint ph(c.step_mode ? prof::ATTN_SELF : prof::ATTN_PREFILL);
       NMTGAN_TRY(launch_attn_rows(&t, st));
     }
-    NMTGAN_TRY(dense_add_ln(g, a.ao, d, M, d, b.o, b.ln0, a.xf, a.yf, a.xo, st, img, img));
-    NMTGAN_TRY(dense1(op, a.xo, d, M, d, d, b.cq, a.q, d, 0, qscale, 0, st, img));
+    NMTGAN_TRY(dense_add_ln(g, sp, a.ao, d, M, d, b.o, b.ln0, a.xf, a.yf, a.xo, st, img, img));
+    NMTGAN_TRY(dense1(op, sp, a.xo, d, M, d, d, b.cq, a.q, d, 0, qscale, 0, st, img));
     if (img && (split_ablate() & 8)) NMTGAN_TRY(launch_round_f16(a.q, (int64_t)M * d, st));
     if (c.group_R > 0) {
       nmtgan_attn_group_args ga{};
@@ -282,26 +283,27 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       prof::Hint ph(c.step_mode ? prof::ATTN_CROSS : prof::ATTN_PREFILL);
       NMTGAN_TRY(launch_attn_rows(&t, st));
     }
-    NMTGAN_TRY(dense_add_ln(g, a.ao, d, M, d, b.co, b.ln1, a.xf, a.yf, a.xo, st, img, img));
+    NMTGAN_TRY(dense_add_ln(g, sp, a.ao, d, M, d, b.co, b.ln1, a.xf, a.yf, a.xo, st, img, img));
     {
       prof::Hint ph(prof::GEMM_FFN);
       if (img) {                                   // hidden layer straight into its operand image [M][12 d]
         NMTGAN_REQUIRE((size_t)M * 12 * d * sizeof(f16_t) <= a.split_bytes, "decoder: split scratch too small");
-        NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.split, 12 * (int64_t)d, 2, 1.f, 1, st, img));
-        NMTGAN_TRY(dense_add_ln(g, a.h, 4 * d, M, 4 * d, b.ffn2, b.ln2, a.xf, a.yf, a.xo, st, a.split, img));
+        NMTGAN_TRY(dense1(op, sp, a.xo, d, M, d, 4 * d, b.ffn1, a.split, 12 * (int64_t)d, 2, 1.f, 1, st, img));
+        NMTGAN_TRY(dense_add_ln(g, sp, a.h, 4 * d, M, 4 * d, b.ffn2, b.ln2, a.xf, a.yf, a.xo, st, a.split, img));
       } else {
-        NMTGAN_TRY(dense1(op, a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
-        NMTGAN_TRY(dense_add_ln(g, a.h, 4 * d, M, 4 * d, b.ffn2, b.ln2, a.xf, a.yf, a.xo, st));
+        NMTGAN_TRY(dense1(op, sp, a.xo, d, M, d, 4 * d, b.ffn1, a.h, 4 * d, 0, 1.f, 1, st));
+        NMTGAN_TRY(dense_add_ln(g, sp, a.h, 4 * d, M, 4 * d, b.ffn2, b.ln2, a.xf, a.yf, a.xo, st));
       }
     }
   }
   return 0;
 }
 
-static int logits_gemm(const nmtgan_generator* g, const void* x_op, int M, float* logits, hipStream_t st) {
+static int logits_gemm(const nmtgan_generator* g, const SplitCtx* sp, const void* x_op, int M, float* logits,
+                       hipStream_t st) {
   nmtgan_dense w{g->softmax_w, nullptr};
   prof::Hint ph(prof::GEMM_LOGITS);
-  return dense1(g->op_dtype, x_op, g->d, M, g->d, g->vocab_dst, w, logits, g->vocab_dst, 1, 1.f, 0, st);
+  return dense1(g->op_dtype, sp, x_op, g->d, M, g->d, g->vocab_dst, w, logits, g->vocab_dst, 1, 1.f, 0, st);
 }
 
 // teacher-forced decoder over dec_in[B][T]; writes shared K/V and leaves the final states in a.xo
@@ -313,7 +315,7 @@ static int prefill(const nmtgan_generator* g, const int32_t* dec_in, const uint8
   e.table = g->emb_dst; e.timing = g->timing; e.vocab = g->vocab_dst; e.max_pos = g->max_pos;
   e.tok = dec_in; e.tok_ld = 1; e.pos_mod = T; e.mult = 2.0f * g->emb_mult;      // model.py:565 (quirk B.2)
   e.M = M; e.d = d; e.out_f32 = a.xf; e.out_op = a.xo; e.op_dtype = g->op_dtype;
-  e.out_split = (g->gemm_split && g_split_buf) ? a.img : nullptr;
+  e.out_split = a.sp() ? a.img : nullptr;
   NMTGAN_TRY(launch_embed(&e, st));
   DecAttn c{};
   c.shK = shK; c.shV = shV; c.len_sh = T; c.sh_layer_stride = (int64_t)M * d; c.rows_per_blk = T; c.causal = 1;
@@ -336,15 +338,19 @@ static int check_disc(const nmtgan_discriminator* d) {
     f += d->n_filters[i];
   }
   NMTGAN_REQUIRE(f == d->F, "discriminator: sum(num_filters) != F");
+  NMTGAN_REQUIRE(!d->gemm_split || d->op_dtype == NMTGAN_F16, "discriminator: gemm_split needs op_dtype NMTGAN_F16");
   return 0;
 }
+// elements per token of the sentence image (and per tap of a filter): the split-precision form interleaves the
+// [hi | lo | hi] / [hi | hi | lo] parts per token / tap, so a window of w tokens stays one contiguous slice
+static inline int disc_ew(const nmtgan_discriminator* d) { return d->gemm_split ? 3 * d->dim_word : d->dim_word; }
 
 struct DiscBufs { void* e; float* pooled; void* pooled_op; float* ho; float* ht; };
 static void carve_disc(Arena& ar, const nmtgan_discriminator* d, int chunk, DiscBufs& b) {
   const int es = dtype_size(d->op_dtype);
-  b.e = ar.take((int64_t)chunk * d->max_len * d->dim_word * es);
+  b.e = ar.take((int64_t)chunk * d->max_len * disc_ew(d) * es);
   b.pooled = ar.get<float>((int64_t)chunk * d->Fp);
-  b.pooled_op = ar.take((int64_t)chunk * d->Fp * es);
+  b.pooled_op = ar.take((int64_t)chunk * d->Fp * es * (d->gemm_split ? 3 : 1));
   b.ho = ar.get<float>((int64_t)chunk * d->Fp);
   b.ht = ar.get<float>((int64_t)chunk * d->Fp);
 }
@@ -378,7 +384,7 @@ static int bucket_delta(const nmtgan_reward_plan* p) {          // NMTGAN_CONV_B
 static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* ids,
                                int rows, float* feat, DiscBufs& b, hipStream_t st, const PrefixReuse* reuse = nullptr,
                                const BucketReuse* bk = nullptr) {
-  const int T = d->max_len, E = d->dim_word, Fp = d->Fp, op = d->op_dtype;
+  const int T = d->max_len, E = disc_ew(d), Fp = d->Fp, op = d->op_dtype;
   NMTGAN_TRY(launch_disc_embed(tw.emb, op, &tw == &d->src ? d->vocab_s : d->vocab, ids, (int64_t)rows * T, E, b.e, st));
   if (reuse) {
     NMTGAN_TRY(launch_pool_init(reuse->pm, reuse->row_b, reuse->row_g, rows, T, Fp, b.pooled, st));
@@ -461,12 +467,19 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
     }
     col += d->n_filters[i];
   }
-  NMTGAN_TRY(launch_cast_rows(b.pooled, b.pooled_op, op, (int64_t)rows * Fp, st));
+  // highway input in the operand type; split form: pooled as [hi | lo | hi] against Wt[Fp][3 Fp] = [hi | hi | lo]
+  const int Kh = d->gemm_split ? 3 * Fp : Fp;
+  if (d->gemm_split) {
+    prof::Hint ph(prof::DISC_SMALL);
+    NMTGAN_TRY(launch_split3(b.pooled, Fp, rows, Fp, b.pooled_op, st));
+  } else {
+    NMTGAN_TRY(launch_cast_rows(b.pooled, b.pooled_op, op, (int64_t)rows * Fp, st));
+  }
   nmtgan_dense wo{tw.hw_out, nullptr}, wt{tw.hw_tr, nullptr};
   {
     prof::Hint ph(prof::GEMM_HIGHWAY);
-    NMTGAN_TRY(dense1(op, b.pooled_op, Fp, rows, Fp, Fp, wo, b.ho, Fp, 1, 1.f, 0, st));
-    NMTGAN_TRY(dense1(op, b.pooled_op, Fp, rows, Fp, Fp, wt, b.ht, Fp, 1, 1.f, 0, st));
+    NMTGAN_TRY(dense1(op, nullptr, b.pooled_op, Kh, rows, Kh, Fp, wo, b.ho, Fp, 1, 1.f, 0, st));
+    NMTGAN_TRY(dense1(op, nullptr, b.pooled_op, Kh, rows, Kh, Fp, wt, b.ht, Fp, 1, 1.f, 0, st));
   }
   return launch_highway_gate(b.pooled, b.ho, b.ht, feat, (int64_t)rows * Fp, st);
 }
@@ -475,7 +488,7 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
 // taps [(c-1)*delta, c*delta) of every window, then prefix sums over c
 static int bucket_tables(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* y, int B,
                          const BucketReuse& bk, hipStream_t st) {
-  const int T = d->max_len, E = d->dim_word, op = d->op_dtype, es = dtype_size(op), dl = bk.delta;
+  const int T = d->max_len, E = disc_ew(d), op = d->op_dtype, es = dtype_size(op), dl = bk.delta;
   NMTGAN_TRY(launch_disc_embed(tw.emb, op, d->vocab, y, (int64_t)B * T, E, bk.ye, st));
   for (int i = 0; i < d->n_widths; ++i) {
     const int w = d->widths[i], N = d->n_filters[i], Pw = T - w + 1;
@@ -502,7 +515,7 @@ static int bucket_tables(const nmtgan_discriminator* d, const nmtgan_disc_tower&
 // a pooling group of one window; windows that run over a sentence end are computed and never read)
 static int disc_window_values(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* ids, int rows,
                               float* Cw, DiscBufs& b, hipStream_t st) {
-  const int T = d->max_len, E = d->dim_word, Fp = d->Fp, op = d->op_dtype;
+  const int T = d->max_len, E = disc_ew(d), Fp = d->Fp, op = d->op_dtype;
   NMTGAN_TRY(launch_disc_embed(tw.emb, op, d->vocab, ids, (int64_t)rows * T, E, b.e, st));
   NMTGAN_TRY(launch_zero(Cw, (size_t)rows * T * Fp * sizeof(float), st));
   int col = 0;
@@ -653,9 +666,10 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
     max_n = d->n_filters[i] > max_n ? d->n_filters[i] : max_n;
   }
   const int dl = bucket_delta(p);
-  if (b.reuse && dl > 0 && (d->dim_word * es) % 128 == 0 && (max_w - 1) / dl < BUCKET_MAX_C && max_w > dl) {
+  const int des = dtype_size(d->op_dtype);
+  if (b.reuse && dl > 0 && (d->dim_word * des) % 128 == 0 && (max_w - 1) / dl < BUCKET_MAX_C && max_w > dl) {
     b.bucket.delta = dl;
-    b.bucket.ye = ar.take((size_t)p->B * p->T * d->dim_word * es);
+    b.bucket.ye = ar.take((size_t)p->B * p->T * disc_ew(d) * des);
     int64_t off = 0;
     for (int i = 0; i < d->n_widths; ++i)
       for (int c = 1; c * dl <= d->widths[i] - 1 && c < BUCKET_MAX_C; ++c) {
@@ -673,10 +687,12 @@ static int check_plan(const nmtgan_generator* g, const nmtgan_discriminator* d, 
   NMTGAN_TRY(check_generator(g));
   NMTGAN_TRY(check_disc(d));
   NMTGAN_REQUIRE(p != nullptr, "plan: null");
-  // the two networks share no activation buffer; the split-precision generator (fp32 storage) pairs with a 16-bit
-  // discriminator, every other tier packs both alike
-  NMTGAN_REQUIRE(g->op_dtype == d->op_dtype || g->gemm_split,
-                 "generator and discriminator must be packed in the same op dtype");
+  // the two networks share no activation buffer and no scratch; the split-precision generator (fp32 storage, fp16
+  // products) pairs with a 16-bit discriminator (plain or split form), every other tier packs both alike
+  if (g->gemm_split)
+    NMTGAN_REQUIRE(dtype_size(d->op_dtype) == 2, "a gemm_split generator pairs with a 16-bit discriminator (plain or gemm_split)");
+  else
+    NMTGAN_REQUIRE(g->op_dtype == d->op_dtype, "generator and discriminator must be packed in the same op dtype");
   NMTGAN_REQUIRE(p->B > 0 && p->Ls > 0 && p->T > 1 && p->rollnum > 0, "plan: bad B/Ls/T/rollnum");
   NMTGAN_REQUIRE(p->T == d->max_len, "plan: max_len %d != discriminator max_len %d", p->T, d->max_len);
   NMTGAN_REQUIRE(p->Ls <= g->max_pos && p->T <= g->max_pos, "plan: length exceeds timing table");
@@ -717,14 +733,13 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
   NMTGAN_TRY(carve_reward(ar, g, d, p, b));
   NMTGAN_REQUIRE(ws != nullptr && !ar.overflow, "rollout_reward: workspace too small (%zu < %zu)", ws_bytes, ar.off);
   const int B = p->B, Ls = p->Ls, T = p->T, dm = g->d, V = g->vocab_dst, op = g->op_dtype;
-  SplitScope split_gemm(g, b.act.split, b.act.split_bytes);
-
+  
   // 1. encoder once, cross K/V once per block (the reference re-encodes on every sess.run)
   NMTGAN_TRY(encode(g, p->x, p->x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
-  NMTGAN_TRY(cross_kv(g, b.act.xo, B * Ls, b.crossK, b.crossV, st));
+  NMTGAN_TRY(cross_kv(g, b.act.sp(), b.act.xo, B * Ls, b.crossK, b.crossV, st));
   // 2. teacher-forced pass over y_sample: shared K/V of positions 0..T-1 and the prefix logits
   NMTGAN_TRY(prefill(g, p->dec_in, p->x_pad, B, Ls, T, b.act, b.shK, b.shV, b.crossK, b.crossV, st));
-  NMTGAN_TRY(logits_gemm(g, b.act.xo, B * T, b.prefix_logits, st));
+  NMTGAN_TRY(logits_gemm(g, b.act.sp(), b.act.xo, B * T, b.prefix_logits, st));
   if (b.group_R > 0) {                 // transposed copies of the shared values for the MFMA group kernel
     const int es = dtype_size(op);
     for (int l = 0; l < g->n_blocks; ++l) {
@@ -852,7 +867,7 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
                                         b.fused_ws, st));
       } else for (int r0 = 0; r0 < M; r0 += (int)b.logits_rows) {
         const int rows = M - r0 < b.logits_rows ? M - r0 : (int)b.logits_rows;
-        NMTGAN_TRY(logits_gemm(g, at(b.act.xo, (int64_t)r0 * dm, dtype_size(op)), rows, b.logits, st));
+        NMTGAN_TRY(logits_gemm(g, b.act.sp(), at(b.act.xo, (int64_t)r0 * dm, dtype_size(op)), rows, b.logits, st));
         nmtgan_sample_args q{};
         q.logits = b.logits; q.ld = V; q.V = V; q.M = rows;
         q.u = p->uniforms; q.u_off = p->row_uoff + r0; q.u_add = step; q.out = b.tok_cur + r0;
@@ -904,11 +919,10 @@ int teacher_forced_logits(const nmtgan_generator* g, const int32_t* x, const uin
   TfBufs b;
   carve_tf(ar, g, B, Ls, T, b);
   NMTGAN_REQUIRE(ws != nullptr && !ar.overflow, "teacher_forced: workspace too small (%zu < %zu)", ws_bytes, ar.off);
-  SplitScope split_gemm(g, b.act.split, b.act.split_bytes);
-  NMTGAN_TRY(encode(g, x, x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
-  NMTGAN_TRY(cross_kv(g, b.act.xo, B * Ls, b.crossK, b.crossV, st));
+    NMTGAN_TRY(encode(g, x, x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
+  NMTGAN_TRY(cross_kv(g, b.act.sp(), b.act.xo, B * Ls, b.crossK, b.crossV, st));
   NMTGAN_TRY(prefill(g, dec_in, x_pad, B, Ls, T, b.act, b.shK, b.shV, b.crossK, b.crossV, st));
-  return logits_gemm(g, b.act.xo, B * T, logits, st);
+  return logits_gemm(g, b.act.sp(), b.act.xo, B * T, logits, st);
 }
 
 // ------------------------------------------------------------------------------------------ greedy generation
@@ -962,9 +976,8 @@ int generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* 
   carve_greedy(ar, g, B, Ls, T, b);
   NMTGAN_REQUIRE(ws != nullptr && !ar.overflow, "generate: workspace too small (%zu < %zu)", ws_bytes, ar.off);
   const int dm = g->d, V = g->vocab_dst, op = g->op_dtype;
-  SplitScope split_gemm(g, b.act.split, b.act.split_bytes);
-  NMTGAN_TRY(encode(g, x, x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
-  NMTGAN_TRY(cross_kv(g, b.act.xo, B * Ls, b.crossK, b.crossV, st));
+    NMTGAN_TRY(encode(g, x, x_pad, B, Ls, b.act, b.kbuf, b.vbuf, st));
+  NMTGAN_TRY(cross_kv(g, b.act.sp(), b.act.xo, B * Ls, b.crossK, b.crossV, st));
   const int nfill = T > B ? T : B;
   hipLaunchKernelGGL(fill_greedy_tables, dim3((nfill + 255) / 256), dim3(256), 0, st, b.step_off, T, B, b.bos, b.zeros,
                      b.blk);
@@ -987,7 +1000,7 @@ int generate_greedy(const nmtgan_generator* g, const int32_t* x, const uint8_t* 
     c.crossK = b.crossK; c.crossV = b.crossV; c.Ls = Ls; c.cross_layer_stride = (int64_t)B * Ls * dm;
     c.cross_blk = b.blk; c.x_pad = x_pad; c.step_mode = 1;
     NMTGAN_TRY(decoder_pass(g, B, b.act, c, st));
-    NMTGAN_TRY(logits_gemm(g, b.act.xo, B, b.logits, st));
+    NMTGAN_TRY(logits_gemm(g, b.act.sp(), b.act.xo, B, b.logits, st));
     nmtgan_sample_args q{};
     q.logits = b.logits; q.ld = V; q.V = V; q.M = B; q.greedy = 1; q.out = b.tok_cur;
     NMTGAN_TRY(launch_sample_rows(&q, st));

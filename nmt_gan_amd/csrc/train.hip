@@ -1081,6 +1081,7 @@ static void carve_dt(Arena& ar, const nmtgan_discriminator* d, int M, DtBufs& b)
 static int check_dt(const nmtgan_discriminator* d, const nmtgan_disc_params* p, const nmtgan_disc_params* g, int M) {
   NMTGAN_REQUIRE(d && p && g, "disc_train: null argument");
   NMTGAN_REQUIRE(d->op_dtype == NMTGAN_BF16 || d->op_dtype == NMTGAN_F32, "disc_train: bad op_dtype");
+  NMTGAN_REQUIRE(!d->gemm_split, "disc_train: the split-precision form is a scoring form (train on a bf16 / fp32 copy)");
   NMTGAN_REQUIRE(d->n_widths > 0 && d->n_widths <= NMTGAN_MAX_WIDTHS && d->max_len > 0 && d->dim_word > 0 && d->dim_word % 8 == 0,
                  "disc_train: bad geometry (dim_word must be a multiple of 8)");
   NMTGAN_REQUIRE(d->Fp % 64 == 0 && d->F <= d->Fp && M > 0, "disc_train: bad F/Fp/M");

@@ -614,6 +614,7 @@ class Model(object):
         """Host half of get_reward: build the rollout plan, upload ids/tables, size the workspace.
         Returns a PreparedReward whose launch() only enqueues device work (inputs resident in HBM)."""
         dev = self.device
+        check_pairing(self.precision, getattr(disc, "precision", None))
         x = np.ascontiguousarray(np.asarray(x), dtype=np.int32)
         B, Ls = x.shape
         plan = build_rollout_plan(mask, rollnum, b_offset=b_offset, B_global=B if B_global is None else B_global,
@@ -689,6 +690,21 @@ class Model(object):
 
     def get_reward_Obinforced(self, *a, **k):
         raise NotImplementedError("get_reward_Obinforced is never called by the reference drivers")
+
+
+def check_pairing(gen_precision, disc_precision):
+    """The tiers that may score together (mirrors the library's plan check): a split-precision generator (fp32
+    storage, fp16 products) pairs with a 16-bit discriminator - plain fp16 / bf16 or the split form 'fp16x3' -, every
+    other generator with a discriminator of its own operand type ('fp16' also with the split-form discriminator, whose
+    operands are fp16).  In particular Model('fp16x3') + DisCNN('fp32') is refused: the two would not share an
+    operand type anywhere and the library has no such path."""
+    if disc_precision is None:
+        return
+    ok = {_lib.SPLIT_PRECISION: ("fp16", "bf16", _lib.SPLIT_PRECISION), "fp16": ("fp16", _lib.SPLIT_PRECISION),
+          "bf16": ("bf16",), "fp32": ("fp32",)}
+    if disc_precision not in ok.get(gen_precision, ()):
+        raise ValueError("Model(precision=%r) cannot score with DisCNN(precision=%r); allowed: %s"
+                         % (gen_precision, disc_precision, ", ".join(ok.get(gen_precision, ()))))
 
 
 class PreparedReward(object):

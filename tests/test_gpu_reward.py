@@ -63,7 +63,7 @@ def test_teacher_forced_logits(cuda, setup, precision, tol):
     assert err < tol, err
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("fp16", 3e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("fp16x3", 1e-5), ("fp16", 3e-3), ("bf16", 2e-2)])
 def test_discriminator_forward(cuda, setup, precision, tol):
     s = setup
     _, disc = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], precision, T)
@@ -145,8 +145,9 @@ def test_get_reward_no_bias_fp32(cuda, setup):
 
 # 16-bit tiers on the tiny near-uniform model (V = 512): (token agreement floor, P(real) abs error) as measured
 # on MI355X with margin; the benchmark-shape figures are asserted in test_gpu_precision_c2.py
-# fp16x3 = split-precision generator (fp32-class logits: only fp32-level near-ties may flip) with an fp16 discriminator
-_TIER_BOUNDS = {"fp16": (0.995, 3e-3), "bf16": (0.92, 2e-2), "fp16x3": (0.9995, 3e-3)}   # bf16 measured 0.933 (d512) - 0.988
+# fp16x3 = split-precision generator (fp32-class logits: only fp32-level near-ties may flip) with the split-precision
+# discriminator (fp32-class scores)
+_TIER_BOUNDS = {"fp16": (0.995, 3e-3), "bf16": (0.92, 2e-2), "fp16x3": (0.9995, 2e-5)}   # bf16 measured 0.933 (d512) - 0.988
 
 
 @pytest.mark.parametrize("precision", ["fp16", "bf16", "fp16x3"])

@@ -43,7 +43,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     pairs = {"nmtgan_gemm_args": (_lib.GemmArgs, "ln_out"), "nmtgan_embed_args": (_lib.EmbedArgs, "out_split"),
              "nmtgan_addln_args": (_lib.AddLnArgs, "out_split"), "nmtgan_attn_args": (_lib.AttnArgs, "out_split"),
              "nmtgan_attn_group_args": (_lib.AttnGroupArgs, "out_split"), "nmtgan_sample_args": (_lib.SampleArgs, "out"),
-             "nmtgan_generator": (_lib.Generator, "gemm_split"), "nmtgan_discriminator": (_lib.Discriminator, "head_b"),
+             "nmtgan_generator": (_lib.Generator, "gemm_split"), "nmtgan_discriminator": (_lib.Discriminator, "gemm_split"),
              "nmtgan_reward_plan": (_lib.RewardPlan, "conv_bucket_taps"),
              "nmtgan_disc_tower_params": (_lib.DiscTowerParams, "hw_tr"), "nmtgan_disc_params": (_lib.DiscParams, "head_b")}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "nmtgan.h"', 'int main(void) {']
@@ -110,6 +110,66 @@ def test_entry_points_validate_before_launch():
     assert _lib.lib.nmtgan_disc_fold_bn(None, None, None, None, None, 4, None, None, None) != 0
     with pytest.raises(_lib.NmtGanError):
         _lib.check(-2, "x")
+
+
+def test_tier_pairing_is_checked_on_both_sides():
+    """A split-precision generator (fp32 storage, fp16 products) scores only with a 16-bit discriminator: the
+    library's plan check refuses an fp32 one before anything is sized or launched, and the facade refuses the same
+    pairs with a Python exception."""
+    from nmt_gan_amd import _lib
+    from nmt_gan_amd.model import check_pairing
+    g = _lib.Generator()
+    g.op_dtype, g.d, g.heads, g.n_blocks, g.vocab_src, g.vocab_dst, g.max_pos = _lib.NMTGAN_F32, 64, 4, 2, 512, 512, 256
+    g.emb_src = g.emb_dst = g.softmax_w = g.timing = 4096
+    g.gemm_split = 1
+    d = _lib.Discriminator()
+    d.op_dtype, d.max_len, d.dim_word, d.vocab, d.vocab_s, d.n_widths, d.F, d.Fp = _lib.NMTGAN_F32, 12, 64, 512, 512, 2, 260, 320
+    d.widths[0], d.widths[1], d.n_filters[0], d.n_filters[1] = 1, 5, 110, 150
+    live = (C.c_int32 * 1)(0)
+    off = (C.c_int64 * 1)(0)
+    p = _lib.RewardPlan()
+    p.B, p.Ls, p.T, p.rollnum, p.n_rows, p.n_steps = 2, 12, 12, 2, 0, 0
+    p.live, p.step_off_host = C.addressof(live), C.addressof(off)
+    assert _lib.lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(d), C.byref(p)) == 0
+    assert b"16-bit discriminator" in _lib.lib.nmtgan_last_error()
+    d.op_dtype = _lib.NMTGAN_F16                                   # plain fp16 and the split form are both accepted
+    assert _lib.lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(d), C.byref(p)) > 0
+    d.gemm_split = 1
+    assert _lib.lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(d), C.byref(p)) > 0
+    d.op_dtype = _lib.NMTGAN_BF16                                  # the split form is made of fp16 products
+    assert _lib.lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(d), C.byref(p)) == 0
+    assert b"gemm_split needs op_dtype NMTGAN_F16" in _lib.lib.nmtgan_last_error()
+    d.gemm_split = 0
+    g.gemm_split, g.op_dtype = 0, _lib.NMTGAN_F16                  # every other tier packs both networks alike
+    assert _lib.lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(d), C.byref(p)) == 0
+    assert b"same op dtype" in _lib.lib.nmtgan_last_error()
+    for gen, disc in (("fp16x3", "fp32"), ("fp16", "fp32"), ("fp32", "fp16"), ("bf16", "fp16x3")):
+        with pytest.raises(ValueError):
+            check_pairing(gen, disc)
+    for gen, disc in (("fp16x3", "fp16x3"), ("fp16x3", "fp16"), ("fp16", "fp16x3"), ("fp32", "fp32"), ("bf16", "bf16")):
+        check_pairing(gen, disc)
+
+
+def test_split_packers_reassemble_the_fp32_values():
+    """The three split layouts (activation rows [hi | lo | hi], weight rows [hi | hi | lo], filters per tap) hold
+    hi + lo = the fp32 value to 2^-22 relative, and the per-tap interleave keeps every tap next to its own lo part."""
+    import torch
+    from nmt_gan_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand((6, 16), generator=g) * 2 - 1
+    img = _lib.split3_acts(a).float()
+    assert img.shape == (6, 48)
+    assert torch.equal(img[:, :16], img[:, 32:]) and float((img[:, :16] + img[:, 16:32] - a).abs().max()) < 2 ** -21
+    w = torch.randn((5, 3 * 8), generator=g) * 0.1                  # 5 filters, 3 taps of E = 8
+    wi = _lib.split3_conv_weights(w, 3).float().view(5, 3, 3, 8)
+    assert torch.equal(wi[:, :, 0], wi[:, :, 1])
+    assert float((wi[:, :, 0] + wi[:, :, 2] - w.view(5, 3, 8)).abs().max()) < 2 ** -24
+    # the split product over the interleaved layouts equals the fp32 product to fp32 rounding
+    e = torch.rand((7, 3, 8), generator=g) * 2 - 1                  # 7 windows of 3 tokens
+    ei = _lib.split3_acts(e.view(21, 8)).float().view(7, 3 * 24)
+    got = ei.double() @ wi.reshape(5, 72).double().T
+    want = e.view(7, 24).double() @ w.double().T
+    assert float((got - want).abs().max()) < 1e-6
 
 
 def test_reference_named_helpers():
