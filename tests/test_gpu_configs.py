@@ -43,9 +43,9 @@ def test_c1_fp32_tier_reproduces_oracle_golden(cuda):
     # At V = 32000 about one draw in 10^4 lies within fp32 rounding of a CDF boundary; such a rollout may leave the
     # oracle's after that token.  It is accepted only as a STATED NEAR-TIE: at the first differing position the
     # uniform lies within 1e-5 of the normalised CDF boundary between the two tokens (fp32-tier logits of the
-    # common prefix, fp64 CDF), and at most 3 rollouts in 856 may do so.
+    # common prefix, fp64 CDF), and at most ONE rollout in 856 may do so (the one case seen: 8e-10 from a boundary).
     bad = np.flatnonzero(~same)
-    assert bad.size <= 3, bad
+    assert bad.size <= 1, bad
     for i in bad:
         b, r_, g_ = int(plan.row_b[i]), int(plan.row_r[i]), int(plan.row_g[i])
         t = int(np.flatnonzero(got[i] != want[i])[0])
@@ -151,19 +151,22 @@ def test_c4_big_model_properties(cuda, precision):
         b, r_, g_ = int(plan.row_b[i]), int(plan.row_r[i]), int(plan.row_g[i])
         bad += int(O.multinomial_cdf(det["prefix_logits"][b, g_], un[r_, g_ - 1, b, g_]) != rolls[i, g_])
     assert bad <= 1, bad
-    # discriminator spot check at T = 80 (20 widths, F = 9800) against the fp64 oracle
-    idx = rng.choice(plan.n_rows, 3, replace=False)
+    # discriminator spot check at T = 80 (20 widths, F = 9800) against the fp64 oracle: 32 rollouts within 1e-3 in the
+    # split-precision tier, 3 within the fp16 tier's 2e-3
+    n_check, tol = {"fp16": (3, 2e-3), "fp16x3": (32, 1e-3)}[precision]
+    idx = rng.choice(plan.n_rows, n_check, replace=False)
     dcfg = O.DisConfig(max_len=T, dim_word=E, vocab_size=V, vocab_size_s=V)
     p = O.disc_forward(O.to_torch(Wd), dcfg, rolls[idx].T, xp[plan.row_b[idx]].T).numpy()[:, 1]
     err = float(np.abs(p - det["p_rows"][idx]).max())
-    print("C4 P(real) abs err vs fp64 oracle: %.3g (P = %s)" % (err, np.round(p, 4)))
-    assert err < 2e-3
+    print("C4 P(real) abs err vs fp64 oracle (%s, %d rollouts): %.3g (P = %s)" % (precision, n_check, err, np.round(p[:6], 4)))
+    assert err < tol
 
 
-def test_c5_gan_step_scoring_at_one_gpus_share(cuda):
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3"])
+def test_c5_gan_step_scoring_at_one_gpus_share(cuda, precision):
     D, BLOCKS, HEADS, V, E, T, R, B = 512, 6, 8, 32000, 512, 50, 16, 128
     from nmt_gan_amd import synthetic
-    N, m, disc, Wd = _facade_pair(D, BLOCKS, HEADS, V, E, T, B, "fp16")
+    N, m, disc, Wd = _facade_pair(D, BLOCKS, HEADS, V, E, T, B, precision)
     x, y_ground = synthetic.synthetic_batch(B, T, V, V, seed=505)
     y_sample = m.generate_step(x)                                           # gan_train.py:91
     y_sample[5, 17] = O.EOS_ID
@@ -184,13 +187,14 @@ def test_c5_gan_step_scoring_at_one_gpus_share(cuda):
     assert np.array_equal(p_gen[:, 1], det["p_base"])
     # fp64 oracle discriminator on a sample of both batches
     rng = np.random.default_rng(9)
-    idx = rng.choice(B, 4, replace=False)
+    idx = rng.choice(B, 4 if precision == "fp16" else 16, replace=False)      # x2 batches = 8 / 32 scored sentences
     dcfg = O.DisConfig(max_len=T, dim_word=E, vocab_size=V, vocab_size_s=V)
     Wd64 = O.to_torch(Wd)
     o_gen = O.disc_forward(Wd64, dcfg, y[idx].T, xp[idx].T).numpy()
     o_ref = O.disc_forward(Wd64, dcfg, yg[idx].T, xp[idx].T).numpy()
     err = max(float(np.abs(o_gen - p_gen[idx]).max()), float(np.abs(o_ref - p_ref[idx]).max()))
-    print("C5 discriminator abs err vs fp64 oracle (generated + reference batch): %.3g" % err)
+    print("C5 discriminator abs err vs fp64 oracle (%s, generated + reference batch, %d sentences): %.3g"
+          % (precision, 2 * idx.size, err))
     assert err < 1e-3
     # rewards follow from the scores by the reference's tail
     plan = det["plan"]

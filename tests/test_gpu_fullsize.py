@@ -40,7 +40,8 @@ def c2(cuda, request):
     u = model.make_uniforms(R, T, B, seed=2024)
     r = model.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u, return_details=True)
     det = model.last_details
-    return dict(model=model, disc=disc, Wd=Wd, x=x, y=y, mask=mask, xp=xp, u=u, r=r, det=det, widths=widths, nfs=nfs)
+    return dict(model=model, disc=disc, Wd=Wd, x=x, y=y, mask=mask, xp=xp, u=u, r=r, det=det, widths=widths, nfs=nfs,
+                precision=request.param)
 
 
 def test_fullsize_shapes_range_and_masking(c2):
@@ -115,9 +116,13 @@ def test_fullsize_schedules_agree(c2):
     # split sums (prefix taps from y_sample + multiplied taps) against unsplit ones: fp32 rounding of the conv sum,
     # amplified on the few rows whose 2-way score is near a 16-bit rounding boundary of a pooled feature
     dp = np.abs(d3["p_rows"] - c2["det"]["p_rows"])
-    print("partial-window reuse vs full windows: |dP| mean %.3g max %.3g" % (dp.mean(), dp.max()))
-    assert dp.mean() < 5e-5 and dp.max() < 3e-2, (dp.mean(), dp.max())
-    assert np.abs(r3 - c2["r"]).max() < 3e-3
+    dr = np.abs(r3 - c2["r"]).max()
+    print("partial-window reuse vs full windows (%s): |dP| mean %.3g max %.3g, rewards %.3g"
+          % (c2["precision"], dp.mean(), dp.max(), dr))
+    # measured (mean |dP|, max |dP|, rewards): fp16 4.1e-6 / 1.3e-3 / 1.1e-4 (a pooled feature that rounds the other way
+    # in fp16 moves a score of |s| ~ 100 visibly); the split form keeps fp32 features: 6.4e-7 / 1.4e-4 / 2.4e-5
+    lim = {"fp16": (2e-5, 5e-3, 5e-4), "fp16x3": (5e-6, 1e-3, 1e-4)}[c2["precision"]]
+    assert dp.mean() < lim[0] and dp.max() < lim[1] and dr < lim[2], (dp.mean(), dp.max(), dr)
     try:
         m.group_slots = False
         r2 = m.get_reward(c2["x"], c2["xp"], c2["y"], c2["mask"], R, c2["disc"], max_len=T, bias_num=0.6,
@@ -189,11 +194,14 @@ def test_fullsize_first_token_matches_cdf_oracle(c2):
 
 
 def test_fullsize_discriminator_spot_check(c2):
-    """P(real) of 6 rollouts + 2 samples recomputed by the fp64 oracle discriminator (2 GFLOP each)."""
+    """P(real) of rollouts + 2 samples recomputed by the fp64 oracle discriminator (2 GFLOP each): 32 rollouts within
+    1e-3 for the split-precision tier (the north star's reward tolerance, on the benchmark's own discriminator weights
+    whose score reaches |s| ~ 100); the fp16 tier's 6 rollouts within its measured 2e-2."""
     det = c2["det"]
     plan = det["plan"]
     rng = np.random.default_rng(6)
-    idx = rng.choice(plan.n_rows, 6, replace=False)
+    n_check, tol = {"fp16": (6, 2e-2), "fp16x3": (32, 1e-3)}[c2["precision"]]
+    idx = rng.choice(plan.n_rows, n_check, replace=False)
     dcfg = O.DisConfig(max_len=T, dim_word=E, vocab_size=V, vocab_size_s=V)
     Wd64 = O.to_torch(c2["Wd"])
     tgt = det["rollouts"][idx]
@@ -202,5 +210,5 @@ def test_fullsize_discriminator_spot_check(c2):
     err = np.abs(p - det["p_rows"][idx]).max()
     pb = O.disc_forward(Wd64, dcfg, c2["y"][:2].T, c2["xp"][:2].T).numpy()[:, 1]
     err_b = np.abs(pb - det["p_base"][:2]).max()
-    print("full-size P(real) abs err: rollouts %.3g, samples %.3g" % (err, err_b))
-    assert err < 2e-2 and err_b < 2e-2
+    print("full-size P(real) abs err (%s, %d rollouts): rollouts %.3g, samples %.3g" % (c2["precision"], n_check, err, err_b))
+    assert err < tol and err_b < tol

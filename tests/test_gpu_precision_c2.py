@@ -41,17 +41,18 @@ PEAK = 5.0
 # Against the north star (1e-3 logits and rewards, 99.5 % tokens): fp16 meets the logits bound on both vehicles and the
 # reward bound with a discriminator whose BatchNorm statistics fit its activations; NO 16-bit tier reaches 99.5 % token
 # agreement at V = 32000 - at a logit error of 1e-3 about one draw in eleven is a near-tie there - only the fp32 tier and
-# the split-precision tier fp16x3 do (measured: logits 2.7e-6 / 2.5e-6, token agreement 100 % / 99.64 %, max |dP(real)|
-# 2.7e-2 / 1.7e-4 and rewards 4.7e-3 / 4.7e-4 - the last two are its fp16 discriminator's).
+# the split-precision tier fp16x3 do (measured: logits 2.7e-6 / 2.5e-6, token agreement 100 % / 99.64 %; with the
+# split-precision discriminator max |dP(real)| 2.4e-4 / 1.8e-6 and rewards 4e-5 / 7e-6 - with the fp16 discriminator it
+# had 2.7e-2 / 1.7e-4 and 4.7e-3 / 4.7e-4, tools/error_budget_disc.py shows every stage of the fp16 form alone breaks 1e-3).
 BOUNDS = {
     ("fp16", "reference-init"): dict(logits_rel=1.2e-3, agree=0.89, p_abs=4e-2, reward_rel=8e-3),
     ("bf16", "reference-init"): dict(logits_rel=1.0e-2, agree=0.62, p_abs=3e-1, reward_rel=6e-2),
     ("fp16", "trained-like"): dict(logits_rel=1.2e-3, agree=0.90, p_abs=4e-4, reward_rel=1e-3),
     ("bf16", "trained-like"): dict(logits_rel=1.0e-2, agree=0.79, p_abs=3e-3, reward_rel=1e-2),
-    # split-precision generator (fp16 products over hi/lo operand splits, fp32 storage) with an fp16 discriminator: the
-    # token bound is the north star's; P(real) and rewards carry the fp16 discriminator's error
-    ("fp16x3", "reference-init"): dict(logits_rel=1.0e-5, agree=0.995, p_abs=4e-2, reward_rel=8e-3),
-    ("fp16x3", "trained-like"): dict(logits_rel=1.0e-5, agree=0.995, p_abs=4e-4, reward_rel=1e-3),
+    # split-precision generator AND discriminator (fp16 products over hi/lo operand splits, fp32 accumulation and
+    # storage): every bound is the north star's - 1e-3 on logits, P(real) and rewards, 99.5 % of the tokens
+    ("fp16x3", "reference-init"): dict(logits_rel=1.0e-5, agree=0.995, p_abs=1e-3, reward_rel=1e-3),
+    ("fp16x3", "trained-like"): dict(logits_rel=1.0e-5, agree=0.995, p_abs=1e-3, reward_rel=1e-3),
 }
 
 
@@ -199,11 +200,18 @@ def test_tier_accuracy_at_benchmark_shape(world, precision, vehicle):
                tokens_compared=int(have.numel()), flips=int(flip.numel()), worst_flip_margin=worst_margin,
                p_real_abs_max=float(dp.max()), p_real_abs_mean=float(dp.mean()),
                p_real_spread=[float(p32.min()), float(np.median(p32)), float(p32.max())], reward_rel_inf=reward_rel)
-    print("C2 accuracy vs fp32 tier:", json.dumps(res))
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", "precision_c2_%s_%s.json" % (precision, vehicle)), "w") as f:
-        json.dump(res, f, indent=1)
     bnd = BOUNDS[(precision, vehicle)]
+    res["asserted_bounds"] = bnd
+    res["north_star"] = dict(logits_rel=1e-3, token_agreement=0.995, reward_rel=1e-3)
+    res["meets_north_star"] = dict(logits=logits_rel <= 1e-3, tokens=agree >= 0.995, rewards=reward_rel <= 1e-3)
+    print("C2 accuracy vs fp32 tier:", json.dumps(res))
+    # the record bench.py's `tiers` block reads: written next to the other committed summaries (and under gpurun_out/,
+    # the directory a GPU run hands back)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for out_dir in (os.path.join(root, "profiles"), os.path.join(root, "gpurun_out")):
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "r3_precision_c2_%s_%s.json" % (precision, vehicle)), "w") as f:
+            json.dump(res, f, indent=1)
     assert worst_margin <= float(np.expm1(2.0 * dmax)) + 1e-6, res          # every flip is a stated near-tie
     assert logits_rel <= bnd["logits_rel"], res
     assert agree >= bnd["agree"], res
