@@ -145,6 +145,37 @@ def committed_mfma_busy(cls, config, precision):
     return out
 
 
+NORTH_STAR = {"logits_rel": 1e-3, "token_agreement": 0.995, "reward_rel": 1e-3}
+
+
+def tier_accuracy(tier):
+    """Measured accuracy of a precision tier at the benchmark shape, from the records tests/test_gpu_precision_c2.py
+    writes and the repository tracks (profiles/r3_precision_c2_<tier>_<vehicle>.json): the WORST of the two test
+    vehicles per quantity, and whether it meets each clause of the stated tolerance (1e-3 relative on logits and
+    rewards, >= 99.5 % token agreement).  16-bit and split tiers are measured against the fp32 tier on 512 replayed
+    rollouts; the fp32 tier against the fp64 oracle.  None when no record is committed."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    recs = []
+    for vehicle in ("reference-init", "trained-like", "fp64-oracle"):
+        path = os.path.join(root, "r3_precision_c2_%s_%s.json" % (tier, vehicle))
+        if os.path.exists(path):
+            recs.append((vehicle, json.load(open(path))))
+    if not recs:
+        return None
+    worst = lambda key, pick: pick(r[key] for _, r in recs if r.get(key) is not None)
+    out = {"logits_rel": worst("logits_rel_inf", max), "token_agreement": worst("token_agreement", min),
+           "reward_rel": worst("reward_rel_inf", max), "p_real_abs": worst("p_real_abs_max", max),
+           "vehicles": [v for v, _ in recs],
+           "source": "profiles/r3_precision_c2_%s_{%s}.json" % (tier, ",".join(v for v, _ in recs))}
+    tol = recs[0][1].get("north_star", NORTH_STAR)          # the fp32 tier's clause is 1e-5, the others' 1e-3
+    out["tolerance"] = tol
+    out["meets_north_star"] = {"logits": out["logits_rel"] <= tol["logits_rel"],
+                               "tokens": out["token_agreement"] >= tol["token_agreement"],
+                               "rewards": out["reward_rel"] <= tol["reward_rel"]}
+    out["meets_north_star"]["all"] = all(out["meets_north_star"].values())
+    return out
+
+
 def cpu_baseline(cfg, Wg, Wd, x, y, seed_u):
     """Reference-structured CPU path (the oracle's structure-faithful torch-CPU fp32 restatement: full
     re-decode per sampled token, all-position logits, encoder + source tower per call) timed on the
@@ -209,9 +240,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32", "fp16x3"],
-                    help="MFMA operand tier: fp16 (default; meets the 1e-3 logits/rewards tolerance), bf16, fp32 (exact), "
-                         "fp16x3 (generator GEMMs as fp16 products over hi/lo operand splits, fp32 storage; fp16 discriminator)")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip timing the same workload on the fp32 parity tier")
+                    help="tier of the headline `value`: fp16 (default: the 16-bit throughput tier; meets the 1e-3 logits "
+                         "tolerance, not the 99.5 %% token clause at V = 32000 - see `tiers`), bf16, fp32 (exact), fp16x3 "
+                         "(generator and discriminator products as fp16 MFMA over hi/lo operand splits, fp32 storage: "
+                         "the fastest tier that meets every clause of the tolerance)")
+    ap.add_argument("--no-fp32-leg", "--no-tier-legs", dest="no_fp32_leg", action="store_true",
+                    help="skip timing the same workload on the other tiers (fp16x3: same steps/warmup; fp32: <= 3 steps)")
     ap.add_argument("--no-call-leg", action="store_true", help="skip timing whole Model.get_reward calls (host half included)")
     ap.add_argument("--batch", type=int, default=None, help="sentences per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -285,9 +319,11 @@ def main():
     prep = model.prepare_reward(x[b0:b1], xp[b0:b1], y[b0:b1], mask[b0:b1], R, disc, T, 0.6, u, b_offset=b0,
                                 B_global=Bg)
 
+    gather_cache = {}                     # send / receive buffers of the all-gather, kept between steps
+
     def step():
         r = prep.launch()
-        return gather_rows(r, bounds, dev) if world > 1 else r
+        return gather_rows(r, bounds, dev, gather_cache, copy=False) if world > 1 else r
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -349,40 +385,57 @@ def main():
             model.get_reward(x, xp, y, mask, R, disc, max_len=T, bias_num=0.6)
         result["get_reward_call_ms"] = round(1e3 * (time.perf_counter() - t2) / args.steps, 2)
 
-    # the same workload on the fp32 parity tier (the reference's arithmetic type), one timed step
-    if rank == 0 and world == 1 and args.precision != "fp32" and not args.no_fp32_leg:
-        m32 = N.Model(mcfg, precision="fp32", device=str(dev))
-        m32.build_rollout_generate(T)
-        m32.init_and_restore(weights=Wg)
-        d32 = N.DisCNN(None, T, 2, V, Bl, cfg["E"], widths, nfs, vocab_size_s=V, precision="fp32", device=str(dev))
-        d32.load_weights(Wd)
-        p32 = m32.prepare_reward(x[b0:b1], xp[b0:b1], y[b0:b1], mask[b0:b1], R, d32, T, 0.6, u, b_offset=b0, B_global=Bg)
-        p32.launch()
-        torch.cuda.synchronize(dev)
-        t3 = time.perf_counter()
-        p32.launch()
-        torch.cuda.synchronize(dev)
-        result["fp32_tier_ms_per_step"] = round(1e3 * (time.perf_counter() - t3), 1)
-        result["fp32_tier_sentences_per_s"] = round(Bl / (time.perf_counter() - t3), 2)
-        del p32, m32, d32
-    # ... and on the split-precision tier (fp16 products over hi/lo operand splits, fp32 storage, fp16 discriminator):
-    # the fastest tier that also meets the 99.5 % token-agreement bound at V = 32000 (tests/test_gpu_precision_c2.py)
-    if rank == 0 and world == 1 and args.precision not in ("fp32", "fp16x3") and not args.no_fp32_leg:
-        ms3 = N.Model(mcfg, precision="fp16x3", device=str(dev))
-        ms3.build_rollout_generate(T)
-        ms3.init_and_restore(weights=Wg)
-        ms3.overlap = model.overlap
-        ps3 = ms3.prepare_reward(x[b0:b1], xp[b0:b1], y[b0:b1], mask[b0:b1], R, disc if args.precision == "fp16" else
-                                 N.DisCNN(None, T, 2, V, Bl, cfg["E"], widths, nfs, vocab_size_s=V, precision="fp16",
-                                          device=str(dev)).load_weights(Wd), T, 0.6, u, b_offset=b0, B_global=Bg)
-        ps3.launch()
-        torch.cuda.synchronize(dev)
-        t4 = time.perf_counter()
-        ps3.launch()
-        torch.cuda.synchronize(dev)
-        result["fp16x3_tier_ms_per_step"] = round(1e3 * (time.perf_counter() - t4), 1)
-        result["fp16x3_tier_sentences_per_s"] = round(Bl / (time.perf_counter() - t4), 2)
-        del ps3, ms3
+    # Every tier on the same workload, timed like the headline (fp16x3: same steps and warm-up; fp32: at most 3 steps
+    # after 1 warm-up - it runs ~1.7 s per step - stated in its entry), with the accuracy each tier was MEASURED at
+    # (tracked records of tests/test_gpu_precision_c2.py) and which clauses of the tolerance it meets.
+    if rank == 0 and world == 1 and not args.no_fp32_leg:
+        def tier_leg(precision, steps, warmup):
+            mt = N.Model(mcfg, precision=precision, device=str(dev))
+            mt.build_rollout_generate(T)
+            mt.init_and_restore(weights=Wg)
+            mt.overlap = model.overlap
+            dt = N.DisCNN(None, T, 2, V, Bl, cfg["E"], widths, nfs, vocab_size_s=V, precision=precision, device=str(dev))
+            dt.load_weights(Wd)
+            pt = mt.prepare_reward(x[b0:b1], xp[b0:b1], y[b0:b1], mask[b0:b1], R, dt, T, 0.6, u, b_offset=b0, B_global=Bg)
+            for _ in range(warmup):
+                pt.launch()
+            torch.cuda.synchronize(dev)
+            tt0 = time.perf_counter()
+            for _ in range(steps):
+                pt.launch()
+            torch.cuda.synchronize(dev)
+            ms = 1e3 * (time.perf_counter() - tt0) / steps
+            del pt, mt, dt
+            return ms
+        tiers = {}
+        for precision in ("fp16", "fp16x3", "fp32"):
+            if precision == args.precision:
+                ms, st_, wu_ = 1e3 * elapsed / args.steps, args.steps, args.warmup
+            elif precision == "fp32":
+                st_, wu_ = min(args.steps, 3), 1
+                ms = tier_leg(precision, st_, wu_)
+            else:
+                st_, wu_ = args.steps, args.warmup
+                ms = tier_leg(precision, st_, wu_)
+            entry = {"ms_per_step": round(ms, 2), "sentences_per_s": round(Bl * 1e3 / ms, 2), "steps": st_, "warmup": wu_}
+            acc = tier_accuracy(precision) if args.config == "c2" else None
+            if acc:
+                entry.update(acc)
+            tiers[precision] = entry
+        result["tiers"] = tiers
+        result["north_star_tolerance"] = NORTH_STAR
+        ok = [t for t in ("fp16", "fp16x3", "fp32") if tiers[t].get("meets_north_star", {}).get("all")]
+        if ok:
+            best = max(ok, key=lambda t: tiers[t]["sentences_per_s"])
+            result["compliant_tier"] = best
+            result["compliant_tier_value"] = tiers[best]["sentences_per_s"]
+        hm = tiers.get(args.precision, {}).get("meets_north_star")
+        if hm is not None:
+            result["value_meets_north_star"] = hm
+        # (names kept from earlier rounds)
+        result["fp32_tier_ms_per_step"] = tiers["fp32"]["ms_per_step"]
+        result["fp16x3_tier_ms_per_step"] = tiers["fp16x3"]["ms_per_step"]
+        result["fp16x3_tier_sentences_per_s"] = tiers["fp16x3"]["sentences_per_s"]
     if args.rehearse:
         result["rehearsal"] = True
 

@@ -246,7 +246,10 @@ int nmtgan_logits_sample(int op_dtype, const void* x, const void* w, int M, int 
  * work list) is a static device array of NMTGAN_LOGITS_SAMPLE_STATIC_BYTES that every GPU the library runs on holds
  * until the process ends.  The call allocates nothing; it fails with a message when
  * nmtgan_logits_sample_workspace_bytes(M, V) exceeds the array (about 8,300 rows at V = 32000).  All calls on one
- * GPU share the array: calls that overlap in time on the same GPU (different streams or threads) race. */
+ * GPU share the array: calls that overlap in time on the same GPU (different streams or threads) race.
+ * The array's address is resolved on the first call on each device (a symbol lookup, which may load the code object):
+ * make that first call OUTSIDE any stream capture - a first call that arrives under capture is refused with a message;
+ * later calls can be captured and replayed.  `stream` must belong to the current device. */
 #define NMTGAN_LOGITS_SAMPLE_STATIC_BYTES (32u << 20)
 int nmtgan_logits_sample_static(int op_dtype, const void* x, const void* w, int M, int V, int d, const float* u,
                                 const int64_t* u_off, int64_t u_add, int32_t* out, void* stream);

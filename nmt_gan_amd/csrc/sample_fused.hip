@@ -284,15 +284,27 @@ __global__ __launch_bounds__(256) void recompute_kernel(RecomputeParams p) {
   if (token >= 0 && n < nrow) p.out[row] = min(tile * 64 + token, p.V - 1);
 }
 
-// Address of `scratch` on the current device, looked up once per device (with that device current).
-static int static_scratch_ptr(void** out) {
+// Address of `scratch` on the current device, looked up once per device (with that device current).  The lookup
+// may load the code object, which is not allowed while a stream is being captured into a HIP graph: a first call on
+// a device that arrives under capture is refused with a message (one warm call outside the capture resolves it).
+static int static_scratch_ptr(void** out, hipStream_t st) {
   static std::mutex mu;
   static void* ptrs[64];
   static bool have[64];
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) NMTGAN_FAIL(-3, "logits_sample_static: no current device");
+  // every GPU holds its own copy of the array: the stream must belong to the device whose address is handed out
+  hipDevice_t sdev = -1;
+  if (st != nullptr && hipStreamGetDevice(st, &sdev) == hipSuccess)
+    NMTGAN_REQUIRE((int)sdev == dev, "logits_sample_static: stream belongs to device %d, the current device is %d",
+                   (int)sdev, dev);
   std::lock_guard<std::mutex> lock(mu);
   if (!have[dev]) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess)
+      NMTGAN_REQUIRE(cs == hipStreamCaptureStatusNone,
+                     "logits_sample_static: first call on device %d arrived under stream capture; call it once "
+                     "outside the capture first (the scratch address is resolved on the first call)", dev);
     void* p = nullptr;
     const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
     if (e != hipSuccess || p == nullptr)
@@ -318,7 +330,7 @@ int launch_logits_sample_static(int op_dtype, const void* x, const void* w, int 
                  "(use nmtgan_logits_sample with a caller workspace, or fewer rows per call)",
                  M, V, need, (size_t)NMTGAN_LOGITS_SAMPLE_STATIC_BYTES);
   void* ws = nullptr;
-  NMTGAN_TRY(static_scratch_ptr(&ws));
+  NMTGAN_TRY(static_scratch_ptr(&ws, st));
   return launch_logits_sample(op_dtype, x, w, M, V, d, u, u_off, u_add, out, ws, st);
 }
 

@@ -15,11 +15,18 @@ def _lib():
     return _lib
 
 
+_TD = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+
+
+def _code(L, op):
+    return {"bf16": L.NMTGAN_BF16, "fp16": L.NMTGAN_F16, "fp32": L.NMTGAN_F32}[op]
+
+
 def _gemm(L, A, Wt, bias=None, relu=0, op="bf16", a_group=0, a_group_stride=0, lda=None, M=None, K=None,
           segs=None, conv=None):
     """Run nmtgan_gemm.  A, Wt torch tensors already in op dtype on the GPU."""
     a = L.GemmArgs()
-    a.op_dtype = L.NMTGAN_BF16 if op == "bf16" else L.NMTGAN_F32
+    a.op_dtype = _code(L, op)
     a.A, a.Wt = A.data_ptr(), Wt.data_ptr()
     N, Kw = Wt.shape
     a.M = A.shape[0] if M is None else M
@@ -48,12 +55,12 @@ def _gemm(L, A, Wt, bias=None, relu=0, op="bf16", a_group=0, a_group_stride=0, l
     return outs
 
 
-@pytest.mark.parametrize("op", ["bf16", "fp32"])
+@pytest.mark.parametrize("op", ["fp16", "bf16", "fp32"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 512), (1, 96, 2048), (257, 1536, 64), (1000, 130, 1088)])
 def test_gemm_linear(cuda, op, M, N, K):
     L = _lib()
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
-    dt = torch.bfloat16 if op == "bf16" else torch.float32
+    dt = _TD[op]
     A = (torch.rand(M, K, generator=g) * 2 - 1).to(dt).to(cuda)
     # asymmetric weights catch a transposed C write (cdna guide section 3)
     Wt = (torch.rand(N, K, generator=g) * 2 - 1 + torch.arange(N)[:, None] * 1e-3).to(dt).to(cuda)
@@ -66,7 +73,7 @@ def test_gemm_linear(cuda, op, M, N, K):
     assert err < tol, (err, tol)
 
 
-@pytest.mark.parametrize("op", ["bf16", "fp32"])
+@pytest.mark.parametrize("op", ["fp16", "bf16", "fp32"])
 @pytest.mark.parametrize("M,N,K,relu", [(10000, 2304, 768, 1), (70000, 512, 512, 0), (9000, 1300, 1024, 0)])
 def test_gemm_persistent_many_tiles(cuda, op, M, N, K, relu):
     """Shapes with more output tiles than CUs: every workgroup of the persistent kernels walks several
@@ -74,7 +81,7 @@ def test_gemm_persistent_many_tiles(cuda, op, M, N, K, relu):
     full against a float64-accumulated torch product of the same operands."""
     L = _lib()
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
-    dt = torch.bfloat16 if op == "bf16" else torch.float32
+    dt = _TD[op]
     A = (torch.rand(M, K, generator=g) * 2 - 1).to(dt).to(cuda)
     Wt = (torch.rand(N, K, generator=g) * 2 - 1 + torch.arange(N)[:, None] * 1e-4).to(dt).to(cuda)
     bias = torch.randn(N, generator=g).to(cuda)
@@ -89,26 +96,50 @@ def test_gemm_persistent_many_tiles(cuda, op, M, N, K, relu):
     assert worst < tol, (worst, tol)
 
 
-def test_gemm_segments_and_scale(cuda):
+@pytest.mark.parametrize("op", ["bf16", "fp16"])
+def test_gemm_segments_and_scale(cuda, op):
     L = _lib()
     g = torch.Generator().manual_seed(3)
     M, d = 70, 64
-    A = torch.randn(M, d, generator=g).bfloat16().to(cuda)
-    Wt = (torch.randn(3 * d, d, generator=g) * 0.2).bfloat16().to(cuda)
+    A = torch.randn(M, d, generator=g).to(_TD[op]).to(cuda)
+    Wt = (torch.randn(3 * d, d, generator=g) * 0.2).to(_TD[op]).to(cuda)
     bias = torch.randn(3 * d, generator=g).to(cuda)
-    q, k, v = _gemm(L, A, Wt, bias=bias, op="bf16", segs=[(d, True, 0.25), (d, False, 1.0), (d, False, 1.0)])
+    q, k, v = _gemm(L, A, Wt, bias=bias, op=op, segs=[(d, True, 0.25), (d, False, 1.0), (d, False, 1.0)])
     ref = A.double() @ Wt.double().T + bias.double()
+    tol = 3e-2 if op == "bf16" else 4e-3                           # output rounding: 2^-9 / 2^-12 relative
     assert (q.double() - ref[:, :d] * 0.25).abs().max() < 1e-4
-    assert (k.double() - ref[:, d:2 * d]).abs().max() < 3e-2       # bf16 output rounding (2^-9 relative)
-    assert (v.double() - ref[:, 2 * d:]).abs().max() < 3e-2
+    assert (k.double() - ref[:, d:2 * d]).abs().max() < tol
+    assert (v.double() - ref[:, 2 * d:]).abs().max() < tol
 
 
-@pytest.mark.parametrize("op", ["bf16", "fp32"])
+@pytest.mark.parametrize("M,N,K", [(300, 1536, 512), (70000, 512, 512), (257, 2048, 512)])
+def test_gemm_fp16_outputs_saturate(cuda, M, N, K):
+    """fp16 output segments beyond the half range are stored as +-65504, never as inf (the wide-store epilogues
+    of both persistent kernels and the small-shape kernel); values inside the range round to nearest."""
+    L = _lib()
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.rand(M, K, generator=g) * 2 - 1).half().to(cuda)
+    Wt = (torch.rand(N, K, generator=g) * 2 - 1).half().to(cuda)
+    bias = torch.zeros(N)
+    bias[::7] = 7.0e4                                              # columns pushed past +65504
+    bias[3::7] = -9.0e4                                            # ... and past -65504
+    bias = bias.to(cuda)
+    (out,) = _gemm(L, A, Wt, bias=bias, op="fp16", segs=[(N, False, 1.0)])
+    assert out.dtype == torch.float16 and bool(torch.isfinite(out).all())
+    ref = (A.double() @ Wt.double().T + bias.double()).clamp(-65504.0, 65504.0)
+    assert float((out[:, ::7].double() - 65504.0).abs().max()) == 0.0
+    assert float((out[:, 3::7].double() + 65504.0).abs().max()) == 0.0
+    inside = ref.abs() < 6.0e4
+    err = ((out.double() - ref).abs() / ref.abs().clamp_min(1.0))[inside].max().item()
+    assert err < 1e-3, err
+
+
+@pytest.mark.parametrize("op", ["fp16", "bf16", "fp32"])
 def test_gemm_convmax(cuda, op):
     """width-w VALID conv + folded BN + ReLU + max over time (cnn_discriminator.py:94-105, 469)."""
     L = _lib()
     g = torch.Generator().manual_seed(11)
-    dt = torch.bfloat16 if op == "bf16" else torch.float32
+    dt = _TD[op]
     S, T, E = 37, 12, 64
     e = (torch.rand(S, T, E, generator=g) * 2 - 1).to(dt).to(cuda)
     col = 0
@@ -260,14 +291,14 @@ def _attn_ref(q, keys, vals, heads):
 
 
 @pytest.mark.parametrize("q_op", [0, 1])
-@pytest.mark.parametrize("kv", ["bf16", "fp32"])
+@pytest.mark.parametrize("kv", ["fp16", "bf16", "fp32"])
 @pytest.mark.parametrize("d,heads", [(64, 4), (256, 4), (512, 8), (1024, 16)])
 def test_attn_rows_two_segments(cuda, kv, d, heads, q_op):
     """shared prefix (per-row block + count, with a padding mask) + private step-major suffix;
     q in fp32 or (q_op) in the K/V dtype as the QKV GEMM writes it."""
     L = _lib()
     g = torch.Generator().manual_seed(d + heads)
-    dt = torch.bfloat16 if kv == "bf16" else torch.float32
+    dt = _TD[kv]
     nblk, len1, M, nsteps = 3, 9, 10, 5
     q = (torch.randn(M, d, generator=g) * 0.3).to(cuda)
     if q_op:
@@ -288,7 +319,7 @@ def test_attn_rows_two_segments(cuda, kv, d, heads, q_op):
     out = torch.empty(Mlive, d, device=cuda, dtype=dt)
     a = L.AttnArgs()
     a.q, a.M, a.d, a.heads, a.q_op_dtype = q.data_ptr(), Mlive, d, heads, q_op
-    a.kv_dtype = L.NMTGAN_BF16 if kv == "bf16" else L.NMTGAN_F32
+    a.kv_dtype = _code(L, kv)
     a.k1, a.v1, a.len1 = k1.data_ptr(), v1.data_ptr(), len1
     a.seg1_blk, a.seg1_cnt, a.mask1 = blk.data_ptr(), cnt.data_ptr(), mask.data_ptr()
     a.k2, a.v2, a.step_off, a.n_steps2 = k2.data_ptr(), v2.data_ptr(), step_off.data_ptr(), nsteps
@@ -303,7 +334,7 @@ def test_attn_rows_two_segments(cuda, kv, d, heads, q_op):
         vs = [v1[b, j] for j in keep] + [v2[so[s] + r] for s in range(nsteps)]
         ref = _attn_ref(q[r].double().cpu(), torch.stack(ks).double().cpu(), torch.stack(vs).double().cpu(), heads)
         err = (out[r].double().cpu() - ref).abs().max().item()
-        assert err < (2e-2 if kv == "bf16" else 2e-5), (r, err)   # bf16: output rounding only
+        assert err < {"bf16": 2e-2, "fp16": 3e-3, "fp32": 2e-5}[kv], (r, err)   # 16-bit: output rounding only
 
 
 def test_attn_rows_causal(cuda):
@@ -459,10 +490,11 @@ def test_reward_reduce(cuda):
         assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("kv", ["bf16", "fp16"])
 @pytest.mark.parametrize("q_bf16", [0, 1])
 @pytest.mark.parametrize("len1,Lp", [(50, 64), (80, 96)])
 @pytest.mark.parametrize("d,heads,R", [(128, 2, 16), (512, 8, 16), (1024, 16, 20), (128, 4, 3), (256, 8, 32), (256, 2, 8)])
-def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16):
+def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16, kv):
     """MFMA group attention (shared keys, bf16) in both output modes: normalised output (cross
     attention with a padding mask) and running state continued by attn_rows over private keys."""
     L = _lib()
@@ -471,11 +503,12 @@ def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16):
     G = 7                                   # groups
     M = G * R
     q = (torch.randn(M, d, generator=g) * 0.3).to(cuda)
+    dt = _TD[kv]
     if q_bf16:
-        q = q.bfloat16()
-    k1 = torch.randn(nblk, len1, d, generator=g).bfloat16().to(cuda)
-    v1 = torch.randn(nblk, len1, d, generator=g).bfloat16().to(cuda)
-    vt = torch.full((nblk, d, Lp), float("nan"), dtype=torch.bfloat16, device=cuda)
+        q = q.to(dt)
+    k1 = torch.randn(nblk, len1, d, generator=g).to(dt).to(cuda)
+    v1 = torch.randn(nblk, len1, d, generator=g).to(dt).to(cuda)
+    vt = torch.full((nblk, d, Lp), float("nan"), dtype=dt, device=cuda)
     L.check(L.lib.nmtgan_transpose_v(v1.data_ptr(), vt.data_ptr(), nblk, len1, Lp, d, L.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(vt[:, :, :len1], v1.transpose(1, 2)) and vt[:, :, len1:].abs().max().item() == 0
@@ -498,8 +531,10 @@ def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16):
         return _attn_ref(q[r].double().cpu(), torch.stack(ks).double().cpu(), torch.stack(vs).double().cpu(), heads)
 
     # --- final mode with mask (counts = full length, like cross attention)
-    out = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device=cuda)
+    out = torch.full((M, d), float("nan"), dtype=dt, device=cuda)
+    tol = (3e-2 if d // heads <= 64 else 5e-2) if kv == "bf16" else 6e-3    # q / p / output rounding of the operand type
     a = L.AttnGroupArgs()
+    a.kv_dtype = _code(L, kv)
     a.q, a.M, a.d, a.heads, a.rows_per_group, a.q_bf16 = q.data_ptr(), M, d, heads, R, q_bf16
     a.k, a.vt, a.len, a.len_padded = k1.data_ptr(), vt.data_ptr(), len1, Lp
     a.row_blk, a.row_cnt, a.mask, a.out = blk.data_ptr(), cnt.data_ptr(), mask_d.data_ptr(), out.data_ptr()
@@ -508,7 +543,7 @@ def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16):
     torch.cuda.synchronize()
     for r in rows_ok[::3]:
         err = (out[r].double().cpu() - ref_row(r, True)).abs().max().item()
-        assert err < (3e-2 if d // heads <= 64 else 5e-2), (r, err)            # bf16 q / p / output rounding
+        assert err < tol, (r, err)
     # --- partial mode, continued over 3 private keys by attn_rows
     o_part = torch.empty(M, d, device=cuda)
     m_part = torch.empty(M, heads, device=cuda)
@@ -518,11 +553,11 @@ def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16):
     L.check(L.lib.nmtgan_attn_group(C.byref(a), L.stream_ptr()))
     nsteps = 3
     step_off = torch.tensor([0, M, 2 * M, 3 * M], dtype=torch.int64, device=cuda)
-    k2 = torch.randn(nsteps * M, d, generator=g).bfloat16().to(cuda)
-    v2 = torch.randn(nsteps * M, d, generator=g).bfloat16().to(cuda)
-    out2 = torch.empty(M, d, dtype=torch.bfloat16, device=cuda)
+    k2 = torch.randn(nsteps * M, d, generator=g).to(dt).to(cuda)
+    v2 = torch.randn(nsteps * M, d, generator=g).to(dt).to(cuda)
+    out2 = torch.empty(M, d, dtype=dt, device=cuda)
     b = L.AttnArgs()
-    b.q, b.M, b.d, b.heads, b.kv_dtype, b.q_op_dtype = q.data_ptr(), M, d, heads, L.NMTGAN_BF16, q_bf16
+    b.q, b.M, b.d, b.heads, b.kv_dtype, b.q_op_dtype = q.data_ptr(), M, d, heads, _code(L, kv), q_bf16
     b.k2, b.v2, b.step_off, b.n_steps2 = k2.data_ptr(), v2.data_ptr(), step_off.data_ptr(), nsteps
     b.o_init, b.m_init, b.l_init, b.out = o_part.data_ptr(), m_part.data_ptr(), l_part.data_ptr(), out2.data_ptr()
     L.check(L.lib.nmtgan_attn_rows(C.byref(b), L.stream_ptr()))
@@ -531,11 +566,12 @@ def test_attn_group_final_and_partial(cuda, d, heads, R, len1, Lp, q_bf16):
         ek = [k2[s * M + r] for s in range(nsteps)]
         ev = [v2[s * M + r] for s in range(nsteps)]
         err = (out2[r].double().cpu() - ref_row(r, False, ek, ev)).abs().max().item()
-        assert err < (3e-2 if d // heads <= 64 else 5e-2), (r, err)
+        assert err < tol, (r, err)
 
 
+@pytest.mark.parametrize("kv", ["bf16", "fp16"])
 @pytest.mark.parametrize("d,heads,R", [(512, 8, 16), (256, 4, 4), (128, 2, 16)])
-def test_attn_group_slot_table(cuda, d, heads, R):
+def test_attn_group_slot_table(cuda, d, heads, R, kv):
     """Slot form: 32 // R groups of one sentence per workgroup (per-slot key counts, dead slots, a
     partially filled entry) must give exactly what the one-group-per-workgroup form gives."""
     L = _lib()
@@ -545,10 +581,11 @@ def test_attn_group_slot_table(cuda, d, heads, R):
     per_blk = 2 * slots + 1                       # groups per sentence: two full entries + one partial
     G = nblk * per_blk
     M = G * R
-    q = (torch.randn(M, d, generator=g) * 0.3).bfloat16().to(cuda)
-    k1 = torch.randn(nblk, len1, d, generator=g).bfloat16().to(cuda)
-    v1 = torch.randn(nblk, len1, d, generator=g).bfloat16().to(cuda)
-    vt = torch.zeros((nblk, d, Lp), dtype=torch.bfloat16, device=cuda)
+    dt = _TD[kv]
+    q = (torch.randn(M, d, generator=g) * 0.3).to(dt).to(cuda)
+    k1 = torch.randn(nblk, len1, d, generator=g).to(dt).to(cuda)
+    v1 = torch.randn(nblk, len1, d, generator=g).to(dt).to(cuda)
+    vt = torch.zeros((nblk, d, Lp), dtype=dt, device=cuda)
     L.check(L.lib.nmtgan_transpose_v(v1.data_ptr(), vt.data_ptr(), nblk, len1, Lp, d, L.stream_ptr()))
     gblk = torch.arange(nblk, dtype=torch.int32).repeat_interleave(per_blk)
     gcnt = torch.randint(1, len1 + 1, (G,), generator=g, dtype=torch.int32)
@@ -572,9 +609,10 @@ def test_attn_group_slot_table(cuda, d, heads, R):
     def run(use_table, final):
         a = L.AttnGroupArgs()
         a.q, a.M, a.d, a.heads, a.rows_per_group, a.q_bf16 = q.data_ptr(), M_live, d, heads, R, 1
+        a.kv_dtype = _code(L, kv)
         a.k, a.vt, a.len, a.len_padded = k1.data_ptr(), vt.data_ptr(), len1, Lp
         a.row_blk = blk.data_ptr()
-        out = torch.zeros((M, d), dtype=torch.bfloat16, device=cuda)
+        out = torch.zeros((M, d), dtype=dt, device=cuda)
         o_part = torch.zeros(M, d, device=cuda)
         m_part = torch.zeros(M, heads, device=cuda)
         l_part = torch.zeros(M, heads, device=cuda)

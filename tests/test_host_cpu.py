@@ -326,6 +326,15 @@ for _ in range(2):                                 # second call re-uses the cac
     allp = gather_rows(blk, split_bounds(B1 * R1, 2), torch.device("cpu"), cache)
     assert allp.shape == (5, T) and allp[:2].eq(1).all() and allp[2:].eq(2).all()
 assert len(cache) == 1
+# even shards: the gathered rows could alias the cached receive buffer; by default they do not (two successive
+# results own their storage), copy=False hands out the view for callers that consume it at once
+ev = torch.full((2, T), float(rank))
+r1 = gather_rows(ev, [0, 2, 4], torch.device("cpu"), cache)
+r2 = gather_rows(ev + 10, [0, 2, 4], torch.device("cpu"), cache)
+assert r1.data_ptr() != r2.data_ptr() and r1[:2].eq(0).all() and r1[2:].eq(1).all() and r2[2:].eq(11).all()
+v1 = gather_rows(ev, [0, 2, 4], torch.device("cpu"), cache, copy=False)
+v2 = gather_rows(ev + 10, [0, 2, 4], torch.device("cpu"), cache, copy=False)
+assert v1.data_ptr() == v2.data_ptr() and v1[2:].eq(11).all()          # the view follows the buffer
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
