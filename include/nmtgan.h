@@ -98,8 +98,20 @@ typedef struct {
   const float* ln_gamma;     /* [N] */
   const float* ln_beta;      /* [N] */
   void* ln_out;              /* [M][N] op dtype or NULL */
+  /* CONVMAX with an additive term (optional, add != NULL): v = relu((acc + add[(add_blk[r / a_group] * add_rows +
+   * add_row0 + r % a_group) * N + n]) * scale[n] + shift[n]).  The part of a conv window's sum that does not depend on
+   * the rollout - its leading taps lie in the given prefix, equal to y_sample's - comes from a table computed once per
+   * get_reward; add is [blocks][add_rows][N] fp32, add_blk[M / a_group] int32 names the block of each sentence.
+   * Needs K*esize % 128 == 0 and >= 512 bytes. */
+  const float* add; const int32_t* add_blk; int add_rows; int add_row0;
 } nmtgan_gemm_args;
 int nmtgan_gemm(const nmtgan_gemm_args* a, void* stream);
+/* n independent problems in as few launches as possible: one persistent kernel walks the tiles of up to 24 problems
+ * (longest k-loop first), so problems with fewer tiles than the chip has CUs - the per-width, per-row-range conv
+ * products of the discriminator, cnn_discriminator.py:461-477 - fill it together.  All problems share op dtype and
+ * epilogue: CONVMAX (with or without the additive term) or LINEAR with n_seg = 1, an fp32 output and seg_scale 1.
+ * Results are those of n nmtgan_gemm calls (same k order per output element). */
+int nmtgan_gemm_grouped(const nmtgan_gemm_args* a, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Embedding: out[r] = mult * table[tok(r)] + timing[pos(r)]   (fp32 and op-dtype copies).

@@ -24,7 +24,8 @@ class GemmArgs(C.Structure):
                 ("bias", vp), ("relu", i32), ("n_seg", i32), ("seg_width", i32),
                 ("out", vp * 3), ("ldo", i64 * 3), ("out_f32", i32 * 3), ("seg_scale", f32 * 3),
                 ("scale", vp), ("shift", vp), ("pooled", vp), ("ld_pool", i64), ("ldw", i64),
-                ("ln_x", vp), ("ln_gamma", vp), ("ln_beta", vp), ("ln_out", vp)]
+                ("ln_x", vp), ("ln_gamma", vp), ("ln_beta", vp), ("ln_out", vp),
+                ("add", vp), ("add_blk", vp), ("add_rows", i32), ("add_row0", i32)]
 
 
 class EmbedArgs(C.Structure):
@@ -124,6 +125,7 @@ EXPORTS = {
     "nmtgan_version": (i32, []),
     "nmtgan_last_error": (C.c_char_p, []),
     "nmtgan_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "nmtgan_gemm_grouped": (i32, [C.POINTER(GemmArgs), i32, vp]),
     "nmtgan_embed": (i32, [C.POINTER(EmbedArgs), vp]),
     "nmtgan_add_layernorm": (i32, [C.POINTER(AddLnArgs), vp]),
     "nmtgan_split3": (i32, [vp, i64, i32, i32, vp, vp]),

@@ -93,6 +93,9 @@ int nmtgan_profile_stop(double* ms_per_class, int64_t* launches_per_class, int n
 }
 
 int nmtgan_gemm(const nmtgan_gemm_args* a, void* stream) { return launch_gemm(a, (hipStream_t)stream); }
+int nmtgan_gemm_grouped(const nmtgan_gemm_args* a, int n, void* stream) {
+  return launch_gemm_group(a, n, (hipStream_t)stream);
+}
 int nmtgan_embed(const nmtgan_embed_args* a, void* stream) { return launch_embed(a, (hipStream_t)stream); }
 int nmtgan_add_layernorm(const nmtgan_addln_args* a, void* stream) {
   return launch_add_layernorm(a, (hipStream_t)stream);

@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -67,8 +68,13 @@ struct GemmParams {
   int split_k; float* split_part;
   // add + LayerNorm epilogue (gemm_ln_kernel)
   float* ln_x; const float* ln_gamma; const float* ln_beta; void* ln_out;
+  // CONVMAX with an additive term (EPI_CONVADD, grouped kernel): the part of a window's sum that comes from a table
+  // instead of the product - add[(add_blk[r / a_group] * add_rows + add_row0 + r % a_group) * N + n] is added to the
+  // accumulator before scale / shift / ReLU / max
+  const float* add; const int32_t* add_blk; int add_rows; int add_row0;
 };
 constexpr int EPI_STATS = 100;                  // internal: never a value of nmtgan_gemm_args.epilogue
+constexpr int EPI_CONVADD = 101;                // internal: CONVMAX + additive term, chosen when nmtgan_gemm_args.add is set
 
 // acc[I0 + i][J0 + j] += A-fragment i x B-fragment j for one k-half of a k-tile (MT x NT 16x16 tiles).  Consecutive
 // MFMAs go to different accumulators, so the dependent-accumulator latency of the fp32 shape is never exposed.
@@ -175,8 +181,11 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MT][4
         for (int e = 0; e < 4; ++e) {
           const int m = m0 + i * 16 + 4 * fq + e;
           if (m < p.M) {
-            const float v = fmaxf(acc[i][j][e] * sc + sh, 0.f);
             const int g = m / p.a_group;
+            float a = acc[i][j][e];
+            if constexpr (EPI == EPI_CONVADD)
+              if (p.add) a += p.add[((int64_t)p.add_blk[g] * p.add_rows + p.add_row0 + (m - g * p.a_group)) * p.N + n];
+            const float v = fmaxf(a * sc + sh, 0.f);
             if (g != cur_g) {
               if (cur_g >= 0 && cur_v > 0.f)
                 atomicMax(reinterpret_cast<int*>(p.pooled + (int64_t)cur_g * p.ld_pool + n), __float_as_int(cur_v));
@@ -618,6 +627,164 @@ static int launch_pipe(GemmParams p, hipStream_t st) {
   if (const char* e = getenv("NMTGAN_GEMM_SMEM")) smem_use = atoi(e);
   hipLaunchKernelGGL((gemm_pipe_kernel<OpT, EPI>), dim3(grid), dim3(512), smem_use, st, p);
   NMTGAN_CHECK_LAUNCH("gemm_pipe");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ grouped kernel
+// ONE persistent launch over the tiles of up to GROUP_MAX independent GEMM problems (the discriminator's per-width,
+// per-row-range, per-tap-block convolutions, cnn_discriminator.py:461-477: most of them have fewer tiles than the chip
+// has CUs, or a ragged last round of tiles, and launched one by one they leave CUs idle).  Same 256x128 tile, LDS
+// image, three-stage LDS-DMA stream and counted waits as gemm_pipe_kernel; the stream of (tile, k-tile) pairs of a
+// block now runs across problem boundaries: tile L of the launch belongs to the problem whose tile range holds L
+// (problems ordered longest k-loop first by the host, so the long tiles start first), and everything a tile needs -
+// operand pointers, shape, k-tile count and visiting order, epilogue vectors - comes from the problem's entry of the
+// kernel-argument table.  Per output element the k order is the one of the single-problem kernels, so the bits are
+// the same whichever kernel computes a problem.
+constexpr int GROUP_MAX = 24;
+struct GroupProb {
+  const char* A; const char* W;
+  void* out;                                    // CONVMAX / CONVADD: pooled features; LINEAR: fp32 output
+  const float* v0; const float* v1;             // CONVMAX / CONVADD: scale, shift; LINEAR: bias (may be null), unused
+  const float* add; const int32_t* add_blk;     // CONVADD
+  int64_t a_group_stride_b, ldw_b, ld_out, k_step, k_jump;
+  int M, N, nkt, a_group, lda_b, k_inner, ntn, add_rows, add_row0, relu;
+};
+struct GroupParams {
+  int n_prob, n_tiles;
+  int tile_end[GROUP_MAX];                      // cumulative tile counts (ascending)
+  GroupProb prob[GROUP_MAX];
+};
+
+template <typename OpT, int EPI>
+__global__ __launch_bounds__(512) void gemm_group_kernel(GroupParams gp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int G = gridDim.x;
+  const int my_tiles = (gp.n_tiles - (int)blockIdx.x + G - 1) / G;
+
+  // problem and tile coordinates of launch tile L (column tiles fastest: neighbouring workgroups share an A panel)
+  auto locate = [&](int L, int& q, int& tm, int& tn) {
+    int qq = 0;
+    for (int i = 0; i + 1 < gp.n_prob; ++i) qq += L >= gp.tile_end[i] ? 1 : 0;
+    qq = __builtin_amdgcn_readfirstlane(qq);
+    const int first = qq > 0 ? gp.tile_end[qq - 1] : 0;
+    const int ntn = gp.prob[qq].ntn;
+    q = qq;
+    tm = (L - first) / ntn;
+    tn = (L - first) - tm * ntn;
+  };
+
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
+  const char* src[PNINST];
+  int kin = 0, s_inner = 1;                      // k-tile visiting order of the problem the DMA stream is in
+  int64_t s_step = BKB, s_jump = BKB;
+  auto set_src = [&](int L) {
+    int q, tm, tn;
+    locate(L, q, tm, tn);
+    const GroupProb& pr = gp.prob[q];
+    kin = 0;
+    s_inner = pr.k_inner; s_step = pr.k_step; s_jump = pr.k_jump;
+    const int a_group = pr.a_group, M = pr.M, N = pr.N;
+    const int64_t lda_b = pr.lda_b, gs_b = pr.a_group_stride_b, ldw_b = pr.ldw_b;
+    const char* A = pr.A;
+    const char* W = pr.W;
+#pragma unroll
+    for (int j = 0; j < PNINST; ++j) {
+      const int rho = 8 * (wave + j * PNW) + (lane >> 3);
+      const int lc = (lane & 7) ^ ((rho >> 1) & 7);
+      if (rho < PBM) {
+        const int r = min(tm * PBM + rho, M - 1);
+        src[j] = A + (a_group > 0 ? (int64_t)(r / a_group) * gs_b + (int64_t)(r % a_group) * lda_b : (int64_t)r * lda_b) + lc * 16;
+      } else {
+        src[j] = W + (int64_t)min(tn * PBN + rho - PBM, N - 1) * ldw_b + lc * 16;
+      }
+    }
+  };
+  int is_buf = 0;
+  auto issue = [&]() {
+    kin += 1;
+    const bool run_end = kin == s_inner;
+    const int64_t adv = run_end ? s_jump : s_step;
+    if (run_end) kin = 0;
+#pragma unroll
+    for (int j = 0; j < PNINST; ++j) {
+      glds16(src[j], lds_base + is_buf * PSTAGE + (wave + j * PNW) * 1024);
+      src[j] += adv;
+    }
+    is_buf = is_buf == 2 ? 0 : is_buf + 1;
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fc = lane & 15, fq = lane >> 4;
+  const int fsw = (fc >> 1) & 7;
+  const int a_rd = (wm * 64 + fc) * BKB;
+  const int b_rd = (PBM + wn * 64 + fc) * BKB;
+  int cbuf = 0;
+#define NMTGAN_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  auto step = [&](bool do_issue) {
+    __builtin_amdgcn_s_barrier();
+    if (do_issue) issue();
+    compute_tile<OpT>(smem + cbuf * PSTAGE, a_rd, b_rd, fq, fsw, acc);
+    cbuf = cbuf == 2 ? 0 : cbuf + 1;
+  };
+  if (my_tiles <= 0) return;
+  set_src((int)blockIdx.x);
+  issue();
+  issue();
+  for (int t = 0; t < my_tiles; ++t) {
+    const bool has_next = t + 1 < my_tiles;
+    int q, tm, tn;
+    locate((int)blockIdx.x + t * G, q, tm, tn);
+    const int nkt = gp.prob[q].nkt;              // >= 2 (the host checks >= 4)
+    for (int kt = 0; kt < nkt - 2; ++kt) {       // k-tile kt landed, kt+1 in flight, prefetch kt+2
+      NMTGAN_WAIT(PNINST);
+      step(true);
+    }
+    if (has_next) set_src((int)blockIdx.x + (t + 1) * G);
+    NMTGAN_WAIT(PNINST);                         // k-tile nkt-2: prefetch the next tile's k-tile 0
+    step(has_next);
+    if (has_next) NMTGAN_WAIT(PNINST);           // k-tile nkt-1: prefetch the next tile's k-tile 1
+    else NMTGAN_WAIT(0);
+    step(has_next);
+
+    const GroupProb& pr = gp.prob[q];
+    GemmParams v{};                              // the epilogue's view of this tile's problem
+    v.M = pr.M; v.N = pr.N; v.a_group = pr.a_group;
+    if constexpr (EPI == NMTGAN_EPI_LINEAR) {
+      v.bias = pr.v0; v.relu = pr.relu; v.n_seg = 1; v.seg_width = pr.N;
+      v.out[0] = pr.out; v.ldo[0] = pr.ld_out; v.out_f32[0] = 1; v.seg_scale[0] = 1.f;
+    } else {
+      v.scale = pr.v0; v.shift = pr.v1; v.pooled = reinterpret_cast<float*>(pr.out); v.ld_pool = pr.ld_out;
+      v.add = pr.add; v.add_blk = pr.add_blk; v.add_rows = pr.add_rows; v.add_row0 = pr.add_row0;
+    }
+    epilogue<OpT, EPI>(v, acc, tm * PBM + wm * 64, tn * PBN + wn * 64, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#undef NMTGAN_WAIT
+}
+
+template <typename OpT, int EPI>
+static int launch_group(const GroupParams& gp, hipStream_t st) {
+  constexpr int smem = 3 * PSTAGE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_kernel<OpT, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      NMTGAN_FAIL(-3, "gemm: cannot raise dynamic LDS limit");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_group_kernel<OpT, EPI>), dim3(persistent_grid(gp.n_tiles)), dim3(512), smem, st, gp);
+  NMTGAN_CHECK_LAUNCH("gemm_group");
   return 0;
 }
 
@@ -1503,19 +1670,19 @@ int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return rc;
 }
-static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
-  prof::Scope prof_scope(prof::GEMM_PROJ, st);
+// nmtgan_gemm_args -> GemmParams (shape and alignment checks; the epilogue-specific fields of the three public
+// epilogues); shared by the single-problem dispatch and the grouped launch
+static int fill_params(const nmtgan_gemm_args* a, GemmParams& p) {
   NMTGAN_REQUIRE(a != nullptr, "gemm: null args");
   NMTGAN_REQUIRE(valid_op_dtype(a->op_dtype), "gemm: bad op_dtype %d", a->op_dtype);
   NMTGAN_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
-  if (a->M == 0) return 0;
   const int es = dtype_size(a->op_dtype);
   NMTGAN_REQUIRE(a->A && a->Wt, "gemm: null operand");
   NMTGAN_REQUIRE(((int64_t)a->K * es) % 16 == 0, "gemm: K*esize must be a multiple of 16 bytes (K=%d)", a->K);
   NMTGAN_REQUIRE((a->lda * es) % 16 == 0, "gemm: lda*esize must be a multiple of 16 bytes");
   NMTGAN_REQUIRE(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->Wt % 16) == 0, "gemm: operands must be 16-byte aligned");
   NMTGAN_REQUIRE(a->a_group <= 0 || (a->a_group_stride * es) % 16 == 0, "gemm: a_group_stride misaligned");
-  GemmParams p{};
+  p = GemmParams{};
   p.A = (const char*)a->A; p.W = (const char*)a->Wt;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.lda_b = a->lda * es;
@@ -1545,14 +1712,16 @@ static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
                            (uintptr_t)a->out[s] % 16 == 0,
                        "gemm: a split-image segment needs a 16-bit op dtype, width %% 64 == 0 and 16-byte rows of >= 3 widths");
     }
-    NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch<OpT, NMTGAN_EPI_LINEAR>(p, st));
   } else if (a->epilogue == NMTGAN_EPI_CONVMAX) {
     NMTGAN_REQUIRE(a->a_group > 0, "gemm: CONVMAX needs a_group (windows per sentence)");
     NMTGAN_REQUIRE(a->scale && a->shift && a->pooled, "gemm: CONVMAX needs scale/shift/pooled");
     p.scale = a->scale; p.shift = a->shift; p.pooled = a->pooled; p.ld_pool = a->ld_pool;
-    NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch<OpT, NMTGAN_EPI_CONVMAX>(p, st));
-  }
-  if (a->epilogue == NMTGAN_EPI_ADDLN) {
+    if (a->add) {
+      NMTGAN_REQUIRE(a->add_blk && a->add_rows > 0 && a->add_row0 >= 0 && a->add_row0 + a->a_group <= a->add_rows,
+                     "gemm: CONVMAX additive term needs add_blk and 0 <= add_row0, add_row0 + a_group <= add_rows");
+      p.add = a->add; p.add_blk = a->add_blk; p.add_rows = a->add_rows; p.add_row0 = a->add_row0;
+    }
+  } else if (a->epilogue == NMTGAN_EPI_ADDLN) {
     NMTGAN_REQUIRE(gemm_addln_supported(a->op_dtype, a->N, a->K),
                    "gemm: ADDLN needs a 16-bit op dtype, N = 512 and K*esize a multiple of 128 bytes, >= 256 (N=%d K=%d)", a->N, a->K);
     NMTGAN_REQUIRE(a->a_group <= 0, "gemm: ADDLN takes plain rows (a_group = 0)");
@@ -1560,9 +1729,87 @@ static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
     NMTGAN_REQUIRE((uintptr_t)a->ln_x % 16 == 0 && (uintptr_t)a->ln_gamma % 16 == 0 && (uintptr_t)a->ln_beta % 16 == 0 &&
                        (uintptr_t)a->ln_out % 8 == 0, "gemm: ADDLN pointers misaligned");
     p.bias = a->bias; p.ln_x = a->ln_x; p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_out = a->ln_out;
-    NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch_ln<OpT>(p, st));
+  } else {
+    NMTGAN_FAIL(-2, "gemm: unknown epilogue %d", a->epilogue);
   }
-  NMTGAN_FAIL(-2, "gemm: unknown epilogue %d", a->epilogue);
+  return 0;
+}
+
+static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
+  if (a && a->epilogue == NMTGAN_EPI_CONVMAX && a->add) return launch_gemm_group(a, 1, st);   // the additive form lives in the grouped kernel
+  prof::Scope prof_scope(prof::GEMM_PROJ, st);
+  GemmParams p;
+  NMTGAN_TRY(fill_params(a, p));
+  if (a->M == 0) return 0;
+  if (a->epilogue == NMTGAN_EPI_LINEAR) {
+    NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch<OpT, NMTGAN_EPI_LINEAR>(p, st));
+  } else if (a->epilogue == NMTGAN_EPI_CONVMAX) {
+    NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch<OpT, NMTGAN_EPI_CONVMAX>(p, st));
+  }
+  NMTGAN_DISPATCH_OP(a->op_dtype, OpT, return dispatch_ln<OpT>(p, st));
+  return 0;
+}
+
+// Several independent GEMMs of one epilogue kind (CONVMAX, with or without the additive term, or LINEAR with a single
+// fp32 output segment) in as few persistent launches as their count needs (GROUP_MAX problems each), longest k-loop
+// first.  A problem the grouped kernel does not take (k extent not a multiple of 128 bytes, fewer than 4 k-tiles)
+// is launched on its own.  min_tiles > 0: problems with at least that many 256x128 tiles are launched on their own too
+// (the 256x256 kernel serves them better), unless they carry the additive term.
+int launch_gemm_group(const nmtgan_gemm_args* args, int n, hipStream_t st, int min_tiles) {
+  NMTGAN_REQUIRE(n >= 0 && (n == 0 || args != nullptr), "gemm_grouped: bad arguments");
+  if (n == 0) return 0;
+  const int epi = args[0].epilogue, op = args[0].op_dtype;
+  NMTGAN_REQUIRE(epi == NMTGAN_EPI_LINEAR || epi == NMTGAN_EPI_CONVMAX, "gemm_grouped: LINEAR or CONVMAX problems only");
+  std::vector<GemmParams> ps;
+  ps.reserve(n);
+  for (int i = 0; i < n; ++i) {
+    const nmtgan_gemm_args& a = args[i];
+    NMTGAN_REQUIRE(a.epilogue == epi && a.op_dtype == op, "gemm_grouped: problems must share op dtype and epilogue");
+    GemmParams p;
+    NMTGAN_TRY(fill_params(&a, p));
+    if (a.M == 0) continue;
+    const bool fits = p.kbytes % BKB == 0 && p.kbytes / BKB >= 4;
+    const bool lin_ok = epi != NMTGAN_EPI_LINEAR || (a.n_seg == 1 && a.out_f32[0] == 1 && a.seg_scale[0] == 1.f);
+    const int64_t tiles = (int64_t)((p.M + PBM - 1) / PBM) * ((p.N + PBN - 1) / PBN);
+    if (!fits || !lin_ok || (min_tiles > 0 && tiles >= min_tiles && !p.add)) {
+      NMTGAN_REQUIRE(!p.add, "gemm: the additive CONVMAX form needs K*esize %% 128 == 0 and >= 4 k-tiles");
+      NMTGAN_TRY(launch_gemm_impl(&a, st));
+      continue;
+    }
+    ps.push_back(p);
+  }
+  std::stable_sort(ps.begin(), ps.end(), [](const GemmParams& x, const GemmParams& y) { return x.kbytes > y.kbytes; });
+  for (size_t i0 = 0; i0 < ps.size(); i0 += GROUP_MAX) {
+    GroupParams gp{};
+    gp.n_prob = (int)std::min<size_t>(GROUP_MAX, ps.size() - i0);
+    int64_t tiles = 0;
+    for (int i = 0; i < gp.n_prob; ++i) {
+      const GemmParams& p = ps[i0 + i];
+      GroupProb& q = gp.prob[i];
+      q.A = p.A; q.W = p.W;
+      q.a_group_stride_b = p.a_group_stride_b; q.ldw_b = p.ldw_b; q.k_step = p.k_step; q.k_jump = p.k_jump;
+      q.M = p.M; q.N = p.N; q.nkt = p.kbytes / BKB; q.a_group = p.a_group; q.lda_b = (int)p.lda_b; q.k_inner = p.k_inner;
+      q.ntn = (p.N + PBN - 1) / PBN;
+      NMTGAN_REQUIRE(p.lda_b < (int64_t)1 << 31, "gemm_grouped: lda too large");
+      if (epi == NMTGAN_EPI_LINEAR) {
+        q.out = p.out[0]; q.ld_out = p.ldo[0]; q.v0 = p.bias; q.relu = p.relu;
+      } else {
+        q.out = p.pooled; q.ld_out = p.ld_pool; q.v0 = p.scale; q.v1 = p.shift;
+        q.add = p.add; q.add_blk = p.add_blk; q.add_rows = p.add_rows; q.add_row0 = p.add_row0;
+      }
+      tiles += (int64_t)((p.M + PBM - 1) / PBM) * q.ntn;
+      NMTGAN_REQUIRE(tiles < (int64_t)1 << 30, "gemm_grouped: too many tiles");
+      gp.tile_end[i] = (int)tiles;
+    }
+    gp.n_tiles = (int)tiles;
+    prof::Scope prof_scope(prof::GEMM_PROJ, st);
+    if (epi == NMTGAN_EPI_LINEAR) {
+      NMTGAN_DISPATCH_OP(op, OpT, NMTGAN_TRY((launch_group<OpT, NMTGAN_EPI_LINEAR>(gp, st))));
+    } else {
+      NMTGAN_DISPATCH_OP(op, OpT, NMTGAN_TRY((launch_group<OpT, EPI_CONVADD>(gp, st))));
+    }
+  }
+  return 0;
 }
 
 }  // namespace nmtgan

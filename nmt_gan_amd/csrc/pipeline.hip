@@ -368,6 +368,13 @@ static const int REUSE_ROWS = [] { const char* e = getenv("NMTGAN_REUSE_ROWS"); 
 // applies BN + ReLU and folds the max into the pooled features.  Windows closer than delta to the give point (and
 // those behind it) keep the fused conv + max GEMM with all their taps.  -28 % conv FLOPs at T = 50, delta = 8.
 constexpr int BUCKET_MAX_C = 16;
+// Grouped launches of the discriminator's conv products (NMTGAN_CONV_GROUP: 0 = one launch per product as before;
+// default: products of fewer than this many 256x128 tiles share persistent launches, and every partial-window
+// product runs there with the table term added in the epilogue - no raw buffer, no finish kernel)
+static int conv_group_tiles() {
+  static const int v = [] { const char* e = getenv("NMTGAN_CONV_GROUP"); return e ? atoi(e) : 1024; }();
+  return v;
+}
 struct BucketReuse {
   int delta;
   void* ye;                                    // y_sample sentence image [B*T][E], op dtype
@@ -391,6 +398,8 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
   } else {
     NMTGAN_TRY(launch_zero(b.pooled, (size_t)rows * Fp * sizeof(float), st));
   }
+  const int group_tiles = conv_group_tiles();
+  std::vector<nmtgan_gemm_args> grouped;          // conv products of this chunk that share persistent launches
   auto conv_max = [&](int i, int s0, int s1, int p0, int col) -> int {      // fused conv + BN + ReLU + max, all taps
     const int w = d->widths[i], P = T - w + 1 - p0;
     if (P <= 0 || s1 <= s0) return 0;
@@ -400,6 +409,7 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
     a.M = (s1 - s0) * P; a.N = d->n_filters[i]; a.K = w * E;
     a.lda = E; a.a_group = P; a.a_group_stride = (int64_t)T * E;
     a.scale = tw.conv_scale[i]; a.shift = tw.conv_shift[i]; a.pooled = b.pooled + (int64_t)s0 * Fp + col; a.ld_pool = Fp;
+    if (group_tiles > 0) { grouped.push_back(a); return 0; }
     prof::Hint ph(prof::GEMM_CONV);
     return launch_gemm(&a, st);
   };
@@ -453,6 +463,17 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
           a.A = at(b.e, ((int64_t)s0 * T + pa + c * dl) * E, es); a.Wt = at(tw.conv_w[i], (int64_t)c * dl * E, es);
           a.M = (s1 - s0) * nq; a.N = N; a.K = (w - c * dl) * E; a.ldw = (int64_t)w * E;
           a.lda = E; a.a_group = nq; a.a_group_stride = (int64_t)T * E;
+          if (group_tiles > 0 && ((int64_t)a.K * es) % 128 == 0 && (int64_t)a.K * es >= 512) {
+            // the taps taken from y_sample (table S) are added in the epilogue, then BN + ReLU + max as for a whole
+            // window (the grouped kernel's k-tiles are 128 bytes, at least four of them; a shorter product - one or two
+            // taps of a narrow embedding - keeps the raw buffer + finish kernel; which form a product takes depends
+            // on its width and tap block alone, and both add the same fp32 terms in the same order)
+            a.epilogue = NMTGAN_EPI_CONVMAX;
+            a.scale = tw.conv_scale[i]; a.shift = tw.conv_shift[i]; a.pooled = b.pooled + (int64_t)s0 * Fp + col; a.ld_pool = Fp;
+            a.add = bk->S + bk->s_off[i][c]; a.add_blk = reuse->row_b + s0; a.add_rows = Pw; a.add_row0 = pa;
+            grouped.push_back(a);
+            continue;
+          }
           a.n_seg = 1; a.seg_width = N; a.out[0] = bk->raw; a.ldo[0] = N; a.out_f32[0] = 1; a.seg_scale[0] = 1.f;
           {
             prof::Hint ph(prof::GEMM_CONV);
@@ -466,6 +487,10 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
       s0 = s1;
     }
     col += d->n_filters[i];
+  }
+  if (!grouped.empty()) {
+    prof::Hint ph(prof::GEMM_CONV);
+    NMTGAN_TRY(launch_gemm_group(grouped.data(), (int)grouped.size(), st, group_tiles));
   }
   // highway input in the operand type; split form: pooled as [hi | lo | hi] against Wt[Fp][3 Fp] = [hi | hi | lo]
   const int Kh = d->gemm_split ? 3 * Fp : Fp;
@@ -490,22 +515,32 @@ static int bucket_tables(const nmtgan_discriminator* d, const nmtgan_disc_tower&
                          const BucketReuse& bk, hipStream_t st) {
   const int T = d->max_len, E = disc_ew(d), op = d->op_dtype, es = dtype_size(op), dl = bk.delta;
   NMTGAN_TRY(launch_disc_embed(tw.emb, op, d->vocab, y, (int64_t)B * T, E, bk.ye, st));
-  for (int i = 0; i < d->n_widths; ++i) {
-    const int w = d->widths[i], N = d->n_filters[i], Pw = T - w + 1;
-    if (w <= dl) continue;
-    for (int c = 1; c * dl <= w - 1 && c < BUCKET_MAX_C; ++c) {
-      float* Sc = bk.S + bk.s_off[i][c];
-      nmtgan_gemm_args a{};
-      a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
-      a.A = at(bk.ye, (int64_t)(c - 1) * dl * E, es); a.Wt = at(tw.conv_w[i], (int64_t)(c - 1) * dl * E, es);
-      a.M = B * Pw; a.N = N; a.K = dl * E; a.ldw = (int64_t)w * E;
-      a.lda = E; a.a_group = Pw; a.a_group_stride = (int64_t)T * E;
-      a.n_seg = 1; a.seg_width = N; a.out[0] = Sc; a.ldo[0] = N; a.out_f32[0] = 1; a.seg_scale[0] = 1.f;
-      {
+  const int group_tiles = conv_group_tiles();
+  std::vector<nmtgan_gemm_args> grouped;          // every (width, tap block) product first, then the prefix sums over blocks
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < d->n_widths; ++i) {
+      const int w = d->widths[i], N = d->n_filters[i], Pw = T - w + 1;
+      if (w <= dl) continue;
+      for (int c = 1; c * dl <= w - 1 && c < BUCKET_MAX_C; ++c) {
+        float* Sc = bk.S + bk.s_off[i][c];
+        if (pass == 1) {
+          if (c > 1) NMTGAN_TRY(launch_add_inplace(Sc, bk.S + bk.s_off[i][c - 1], (int64_t)B * Pw * N, st));
+          continue;
+        }
+        nmtgan_gemm_args a{};
+        a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
+        a.A = at(bk.ye, (int64_t)(c - 1) * dl * E, es); a.Wt = at(tw.conv_w[i], (int64_t)(c - 1) * dl * E, es);
+        a.M = B * Pw; a.N = N; a.K = dl * E; a.ldw = (int64_t)w * E;
+        a.lda = E; a.a_group = Pw; a.a_group_stride = (int64_t)T * E;
+        a.n_seg = 1; a.seg_width = N; a.out[0] = Sc; a.ldo[0] = N; a.out_f32[0] = 1; a.seg_scale[0] = 1.f;
+        if (group_tiles > 0) { grouped.push_back(a); continue; }
         prof::Hint ph(prof::GEMM_CONV);
         NMTGAN_TRY(launch_gemm(&a, st));
       }
-      if (c > 1) NMTGAN_TRY(launch_add_inplace(Sc, bk.S + bk.s_off[i][c - 1], (int64_t)B * Pw * N, st));
+    }
+    if (pass == 0 && !grouped.empty()) {
+      prof::Hint ph(prof::GEMM_CONV);
+      NMTGAN_TRY(launch_gemm_group(grouped.data(), (int)grouped.size(), st, group_tiles));
     }
   }
   return 0;
@@ -519,6 +554,8 @@ static int disc_window_values(const nmtgan_discriminator* d, const nmtgan_disc_t
   NMTGAN_TRY(launch_disc_embed(tw.emb, op, d->vocab, ids, (int64_t)rows * T, E, b.e, st));
   NMTGAN_TRY(launch_zero(Cw, (size_t)rows * T * Fp * sizeof(float), st));
   int col = 0;
+  const int group_tiles = conv_group_tiles();
+  std::vector<nmtgan_gemm_args> grouped;
   for (int i = 0; i < d->n_widths; ++i) {
     const int w = d->widths[i];
     nmtgan_gemm_args a{};
@@ -526,9 +563,14 @@ static int disc_window_values(const nmtgan_discriminator* d, const nmtgan_disc_t
     a.A = b.e; a.Wt = tw.conv_w[i]; a.M = rows * T - w + 1; a.N = d->n_filters[i]; a.K = w * E;
     a.lda = E; a.a_group = 1; a.a_group_stride = E;
     a.scale = tw.conv_scale[i]; a.shift = tw.conv_shift[i]; a.pooled = Cw + col; a.ld_pool = Fp;
+    col += d->n_filters[i];
+    if (group_tiles > 0) { grouped.push_back(a); continue; }
     prof::Hint ph(prof::GEMM_CONV);
     NMTGAN_TRY(launch_gemm(&a, st));
-    col += d->n_filters[i];
+  }
+  if (!grouped.empty()) {
+    prof::Hint ph(prof::GEMM_CONV);
+    NMTGAN_TRY(launch_gemm_group(grouped.data(), (int)grouped.size(), st, group_tiles));
   }
   return 0;
 }

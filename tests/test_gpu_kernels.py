@@ -163,6 +163,84 @@ def test_gemm_convmax(cuda, op):
     assert pooled[:, col:].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("op", ["fp16", "fp32"])
+def test_gemm_grouped_equals_single_launches(cuda, op):
+    """nmtgan_gemm_grouped: conv problems of different widths, row counts and window ranges in ONE persistent launch
+    give the bits of one nmtgan_gemm call each (same k order per output element); with the additive term (the part of
+    a window's sum that comes from a table) they match the fp64 restatement; LINEAR problems with fp32 output too."""
+    L = _lib()
+    g = torch.Generator().manual_seed(21)
+    dt = _TD[op]
+    T, E, Fp = 20, 64, 1024
+    probs, keep = [], []
+    pooled_g = {}
+    for (S, w, n, p0) in [(37, 5, 150, 0), (300, 9, 190, 3), (5, 17, 270, 0), (64, 13, 230, 2), (1200, 2, 110, 0)]:
+        e = (torch.rand(S, T, E, generator=g) * 2 - 1).to(dt).to(cuda)
+        Wt = (torch.randn(n, w * E, generator=g) * 0.1).to(dt).to(cuda)
+        scale = (1 + 0.3 * torch.randn(n, generator=g)).to(cuda)
+        shift = (0.3 * torch.randn(n, generator=g)).to(cuda)
+        P = T - w + 1 - p0
+        outs = []
+        for _ in range(2):                                          # [0] single launch, [1] grouped
+            pooled = torch.zeros(S, Fp, device=cuda)
+            a = L.GemmArgs()
+            a.op_dtype, a.epilogue = _code(L, op), L.EPI_CONVMAX
+            a.A, a.Wt = e.data_ptr() + p0 * E * e.element_size(), Wt.data_ptr()
+            a.M, a.N, a.K, a.lda, a.a_group, a.a_group_stride = S * P, n, w * E, E, P, T * E
+            a.scale, a.shift, a.pooled, a.ld_pool = scale.data_ptr(), shift.data_ptr(), pooled.data_ptr(), Fp
+            outs.append((a, pooled))
+        L.check(L.lib.nmtgan_gemm(C.byref(outs[0][0]), L.stream_ptr()), "gemm")
+        probs.append(outs[1][0])
+        keep.append((e, Wt, scale, shift, outs))
+    arr = (L.GemmArgs * len(probs))(*probs)
+    L.check(L.lib.nmtgan_gemm_grouped(arr, len(probs), L.stream_ptr()), "gemm_grouped")
+    torch.cuda.synchronize()
+    for e, Wt, scale, shift, outs in keep:
+        assert float(outs[0][1].abs().max()) > 0
+        assert torch.equal(outs[0][1], outs[1][1])
+    # additive term: windows p0 .. p0 + nq - 1 of S sentences, taps from k0 on multiplied, the rest from a table
+    S, w, n, nq, p0, k0, nblk = 90, 9, 190, 3, 4, 2, 7
+    e = (torch.rand(S, T, E, generator=g) * 2 - 1).to(dt).to(cuda)
+    Wt = (torch.randn(n, w * E, generator=g) * 0.1).to(dt).to(cuda)
+    scale = (1 + 0.3 * torch.randn(n, generator=g)).to(cuda)
+    shift = (0.3 * torch.randn(n, generator=g)).to(cuda)
+    Pw = T - w + 1
+    add = torch.randn(nblk, Pw, n, generator=g).to(cuda)
+    blk = torch.randint(0, nblk, (S,), generator=g, dtype=torch.int32).to(cuda)
+    pooled = torch.zeros(S, Fp, device=cuda)
+    a = L.GemmArgs()
+    a.op_dtype, a.epilogue = _code(L, op), L.EPI_CONVMAX
+    a.A = e.data_ptr() + (p0 + k0) * E * e.element_size()
+    a.Wt = Wt.data_ptr() + k0 * E * Wt.element_size()
+    a.M, a.N, a.K, a.ldw, a.lda, a.a_group, a.a_group_stride = S * nq, n, (w - k0) * E, w * E, E, nq, T * E
+    a.scale, a.shift, a.pooled, a.ld_pool = scale.data_ptr(), shift.data_ptr(), pooled.data_ptr(), Fp
+    a.add, a.add_blk, a.add_rows, a.add_row0 = add.data_ptr(), blk.data_ptr(), Pw, p0
+    L.check(L.lib.nmtgan_gemm_grouped(C.byref(a), 1, L.stream_ptr()), "gemm_grouped add")
+    torch.cuda.synchronize()
+    win = e.double().unfold(1, w, 1).permute(0, 1, 3, 2)[:, p0:p0 + nq, k0:].reshape(S, nq, (w - k0) * E)
+    c = win @ Wt.double().view(n, w, E)[:, k0:].reshape(n, -1).T + add.double()[blk.long(), p0:p0 + nq]
+    ref = torch.relu(c * scale.double() + shift.double()).max(dim=1).values
+    assert (pooled[:, :n].double() - ref).abs().max().item() < 2e-4
+    # LINEAR problems with an fp32 output
+    lin, keepl = [], []
+    for (M, N, K) in [(300, 200, 512), (70, 130, 1024), (1000, 64, 256)]:
+        A = (torch.rand(M, K, generator=g) * 2 - 1).to(dt).to(cuda)
+        W = (torch.rand(N, K, generator=g) * 2 - 1).to(dt).to(cuda)
+        single = _gemm(L, A, W, op=op)[0]
+        out = torch.full((M, N), float("nan"), device=cuda)
+        a = L.GemmArgs()
+        a.op_dtype, a.epilogue, a.A, a.Wt, a.M, a.N, a.K, a.lda = _code(L, op), L.EPI_LINEAR, A.data_ptr(), W.data_ptr(), M, N, K, K
+        a.n_seg, a.seg_width = 1, N
+        a.out[0], a.ldo[0], a.out_f32[0], a.seg_scale[0] = out.data_ptr(), N, 1, 1.0
+        lin.append(a)
+        keepl.append((A, W, single, out))
+    arr = (L.GemmArgs * len(lin))(*lin)
+    L.check(L.lib.nmtgan_gemm_grouped(arr, len(lin), L.stream_ptr()), "gemm_grouped linear")
+    torch.cuda.synchronize()
+    for A, W, single, out in keepl:
+        assert torch.equal(single, out)
+
+
 @pytest.mark.parametrize("d", [64, 128, 512, 1024])
 def test_add_layernorm(cuda, d):
     L = _lib()

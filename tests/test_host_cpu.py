@@ -40,7 +40,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     """Every hand-mirrored ctypes struct has the size the C compiler gives the struct of include/nmtgan.h,
     and its last field sits at the same offset (gcc on the header itself)."""
     from nmt_gan_amd import _lib
-    pairs = {"nmtgan_gemm_args": (_lib.GemmArgs, "ln_out"), "nmtgan_embed_args": (_lib.EmbedArgs, "out_split"),
+    pairs = {"nmtgan_gemm_args": (_lib.GemmArgs, "add_row0"), "nmtgan_embed_args": (_lib.EmbedArgs, "out_split"),
              "nmtgan_addln_args": (_lib.AddLnArgs, "out_split"), "nmtgan_attn_args": (_lib.AttnArgs, "out_split"),
              "nmtgan_attn_group_args": (_lib.AttnGroupArgs, "out_split"), "nmtgan_sample_args": (_lib.SampleArgs, "out"),
              "nmtgan_generator": (_lib.Generator, "gemm_split"), "nmtgan_discriminator": (_lib.Discriminator, "gemm_split"),

@@ -1,6 +1,6 @@
 """Micro-benchmark of nmtgan_gemm on the shapes of the C2 workload (HIP events, random data), with torch.matmul
 (hipBLASLt / rocBLAS) on the same box as a YARDSTICK for the dense shapes - a measuring stick only, the library
-never calls it.  usage: python tools/bench_gemm.py [bf16|fp16]"""
+never calls it.  usage: python tools/bench_gemm.py [bf16|fp16] [k512|addln|addln-sweep]"""
 import ctypes as C
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -155,6 +155,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "addln-sweep":       # the row counts of the rollout steps, K = 512
         for M in range(2048, 50177, 2048):
             run_addln(M, 512)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "k512":              # the K = 512 projection family over the rollout row counts,
+        for M in (49152, 24576, 8192, 2048):                     # each beside the torch.matmul yardstick (16-bit output)
+            run("qkv    M%-5d N1536 K512" % M, M, 1536, 512, None, 0)
+            run("cq     M%-5d N512  K512" % M, M, 512, 512, None, 0)
+            run("o      M%-5d N512  K512 (fp32 out)" % M, M, 512, 512, None, 1)
+            run("ffn1   M%-5d N2048 K512" % M, M, 2048, 512, None, 0)
+            run("ffn2   M%-5d N512  K2048 (fp32 out)" % M, M, 512, 2048, None, 1)
         sys.exit(0)
     for s in SHAPES:
         run(*s)
