@@ -408,7 +408,8 @@ typedef struct {
   int conv_bucket_taps;             /* partial-window reuse in the discriminator (needs row_g_host): a conv window that
                                        straddles a rollout's give point takes the sum over its leading prefix taps, in
                                        blocks of this many taps, from one pass over y_sample and only multiplies the
-                                       rest.  0 = default (8), < 0 = off (every such window is multiplied in full) */
+                                       rest.  0 = default (4; 8 when NMTGAN_CONV_GROUP=0 launches every product on its
+                                       own), < 0 = off (every such window is multiplied in full) */
 } nmtgan_reward_plan;
 size_t nmtgan_rollout_reward_workspace_bytes(const nmtgan_generator* g, const nmtgan_discriminator* d,
                                              const nmtgan_reward_plan* plan);

@@ -367,7 +367,7 @@ static const int REUSE_ROWS = [] { const char* e = getenv("NMTGAN_REUSE_ROWS"); 
 // windows p in (g - (c+1)*delta, g - c*delta] with K = (w - c*delta)*E into `raw`, then bucket_finish adds S,
 // applies BN + ReLU and folds the max into the pooled features.  Windows closer than delta to the give point (and
 // those behind it) keep the fused conv + max GEMM with all their taps.  -28 % conv FLOPs at T = 50, delta = 8.
-constexpr int BUCKET_MAX_C = 16;
+constexpr int BUCKET_MAX_C = 64;
 // Grouped launches of the discriminator's conv products (NMTGAN_CONV_GROUP: 0 = one launch per product as before;
 // default: products of fewer than this many 256x128 tiles share persistent launches, and every partial-window
 // product runs there with the table term added in the epilogue - no raw buffer, no finish kernel)
@@ -384,7 +384,10 @@ struct BucketReuse {
 static int bucket_delta(const nmtgan_reward_plan* p) {          // NMTGAN_CONV_BUCKET overrides the plan field
   static const int env = [] { const char* e = getenv("NMTGAN_CONV_BUCKET"); return e ? atoi(e) : -1000; }();
   if (env != -1000) return env;
-  return p->conv_bucket_taps == 0 ? 8 : p->conv_bucket_taps;
+  // default: blocks of 4 taps with grouped launches (a finer cut multiplies fewer prefix taps, and the many small
+  // products it makes share launches: conv 81 -> 79 ms at T = 50; blocks of 2 or 1 lose more to ragged tiles than they
+  // save), blocks of 8 when every product is a launch of its own
+  return p->conv_bucket_taps == 0 ? (conv_group_tiles() > 0 ? 4 : 8) : p->conv_bucket_taps;
 }
 
 // highway features of `rows` sentences ids[rows][T] -> feat[rows][Fp]
