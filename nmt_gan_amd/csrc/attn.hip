@@ -122,8 +122,10 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ 16-bit fast path
-// Same row-per-wave algorithm for bf16 / fp16 caches with d = 512 / 1024 (the rollout step's private-suffix pass,
-// 278 GB of K/V per C2 get_reward), tuned for bytes in flight:
+// Same row-per-wave algorithm for bf16 / fp16 caches with d = 512 / 1024 (the rollout step's self-attention: the
+// shared teacher-forced prefix of the row's sentence - L2-resident, and the four rows of a workgroup belong to one
+// (sentence, prefix) group, so three of four reads hit L1 - followed by the row's private suffix, 278 GB of K/V per C2
+// get_reward), tuned for bytes in flight (workgroups of 8 rows run the same, of 16 rows 10 % slower):
 //  - K/V stay packed (16 B per lane and vector) and the NEXT batch of KB keys is requested before the
 //    current one is consumed, so 2*KB*2 vector loads per wave are in flight across the softmax chain;
 //  - head reductions use DPP (quad_perm / row_half_mirror / row_mirror) instead of ds_bpermute;

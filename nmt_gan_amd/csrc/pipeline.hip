@@ -189,6 +189,17 @@ static int cross_kv(const nmtgan_generator* g, const SplitCtx* sp, const void* e
   return 0;
 }
 
+// Self-attention of the rollout steps.  Default: ONE launch of the per-row kernel over both key segments - the shared
+// teacher-forced prefix (L2-resident; the four rows of a workgroup share it) and the row's private suffix.
+// NMTGAN_SELF_GROUP=1 restores the earlier two-launch form (shared prefix per group on the matrix cores, running
+// (o, m, l) state through HBM, then the per-row kernel over the private suffix): 66.0 against 59.8 ms per C2
+// get_reward in the fp16 tier, 122.0 against 116.8 ms in the split-precision tier, 288 launches more.  Cross attention
+// (every row attends to all Ls encoder positions) keeps the group kernel.
+static bool self_group_pass() {
+  static const bool v = [] { const char* e = getenv("NMTGAN_SELF_GROUP"); return e && atoi(e) != 0; }();
+  return v;
+}
+
 // One decoder pass over M rows that are already embedded in a.xf/a.xo.  Self-attention keys:
 // shared segment (shK/shV, per-row block/count or the causal rows_per_blk form) + private segment.
 struct DecAttn {
@@ -229,7 +240,7 @@ static int decoder_pass(const nmtgan_generator* g, int M, Act& a, const DecAttn&
       if (img && (split_ablate() & 8))
         for (int s = 0; s < 3; ++s) NMTGAN_TRY(launch_round_f16((float*)outs[s], (int64_t)M * d, st));
     }
-    if (c.group_R > 0) {
+    if (c.group_R > 0 && self_group_pass()) {
       // shared prefix keys once per group on MFMA -> running (o, m, l); private suffix per row after
       nmtgan_attn_group_args ga{};
       ga.q = a.q; ga.q_bf16 = 1; ga.kv_dtype = op; ga.M = M; ga.d = d; ga.heads = g->heads; ga.rows_per_group = c.group_R;
@@ -666,11 +677,13 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   b.shVt = b.crossVt = nullptr;
   b.o_part = b.m_part = b.l_part = nullptr;
   if (b.group_R > 0) {
-    b.shVt = ar.take((size_t)N * p->B * dm * b.Tp * es);
     b.crossVt = ar.take((size_t)N * p->B * dm * b.Lsp * es);
-    b.o_part = ar.get<float>(act_rows * dm);
-    b.m_part = ar.get<float>(act_rows * g->heads);
-    b.l_part = ar.get<float>(act_rows * g->heads);
+    if (self_group_pass()) {
+      b.shVt = ar.take((size_t)N * p->B * dm * b.Tp * es);
+      b.o_part = ar.get<float>(act_rows * dm);
+      b.m_part = ar.get<float>(act_rows * g->heads);
+      b.l_part = ar.get<float>(act_rows * g->heads);
+    }
   }
   b.pr_rows = p->n_steps >= 1 ? p->step_off_host[p->n_steps] : 0;
   b.prK = ar.take((size_t)N * b.pr_rows * dm * es);
@@ -788,8 +801,9 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
   if (b.group_R > 0) {                 // transposed copies of the shared values for the MFMA group kernel
     const int es = dtype_size(op);
     for (int l = 0; l < g->n_blocks; ++l) {
-      NMTGAN_TRY(launch_transpose_v(at(b.shV, (int64_t)l * B * T * dm, es), at(b.shVt, (int64_t)l * B * dm * b.Tp, es), B,
-                                    T, b.Tp, dm, es, st));
+      if (b.shVt)
+        NMTGAN_TRY(launch_transpose_v(at(b.shV, (int64_t)l * B * T * dm, es), at(b.shVt, (int64_t)l * B * dm * b.Tp, es), B,
+                                      T, b.Tp, dm, es, st));
       NMTGAN_TRY(launch_transpose_v(at(b.crossV, (int64_t)l * B * Ls * dm, es),
                                     at(b.crossVt, (int64_t)l * B * dm * b.Lsp, es), B, Ls, b.Lsp, dm, es, st));
     }
