@@ -160,10 +160,20 @@ __global__ __launch_bounds__(256) void attn_rows_16_kernel(AttnParams p) {
   const KT* v2 = reinterpret_cast<const KT*>(p.v2) + (int64_t)row * d + lane * EPL;
   const uint8_t* mk = p.mask1 ? p.mask1 + (int64_t)blk * p.len1 : nullptr;
 
+  // fp16 q against an fp16 cache: the products go through v_dot2_f32_f16 (two exact fp16 x fp16 products per
+  // instruction, fp32 accumulation) on the packed registers as loaded, and the score is scaled to log2 units after the
+  // head reduction; every other combination multiplies unpacked fp32 values with q pre-scaled
+  constexpr bool DOT2 = __is_same(KT, f16_t) && __is_same(QT, f16_t);
   float q[EPL];
-  VecIO<QT, EPL>::load(reinterpret_cast<const QT*>(p.q) + (int64_t)row * d + lane * EPL, q);
+  uint4 qp[NV];
+  if constexpr (DOT2) {
 #pragma unroll
-  for (int e = 0; e < EPL; ++e) q[e] *= LOG2E;
+    for (int i = 0; i < NV; ++i) qp[i] = reinterpret_cast<const uint4*>(reinterpret_cast<const KT*>(p.q) + (int64_t)row * d + lane * EPL)[i];
+  } else {
+    VecIO<QT, EPL>::load(reinterpret_cast<const QT*>(p.q) + (int64_t)row * d + lane * EPL, q);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) q[e] *= LOG2E;
+  }
 
   float m = -INFINITY, l = 0.f;                    // m in log2 units
   float o[EPL];
@@ -215,12 +225,23 @@ __global__ __launch_bounds__(256) void attn_rows_16_kernel(AttnParams p) {
       float part = 0.f;
       const bool ok = (okm >> u) & 1;
       if (ok) {
-        float kf[EPL];
-        unpack(kr[u], kf);
+        if constexpr (DOT2) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) part = fmaf(q[e], kf[e], part);
+          for (int i = 0; i < NV; ++i) {
+            part = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, qp[i].x), __builtin_bit_cast(f16x2_t, kr[u][i].x), part, false);
+            part = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, qp[i].y), __builtin_bit_cast(f16x2_t, kr[u][i].y), part, false);
+            part = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, qp[i].z), __builtin_bit_cast(f16x2_t, kr[u][i].z), part, false);
+            part = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, qp[i].w), __builtin_bit_cast(f16x2_t, kr[u][i].w), part, false);
+          }
+        } else {
+          float kf[EPL];
+          unpack(kr[u], kf);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) part = fmaf(q[e], kf[e], part);
+        }
       }
       part = head_sum(part, lph);
+      if constexpr (DOT2) part *= LOG2E;
       s[u] = ok ? part : -INFINITY;
       mx = fmaxf(mx, s[u]);
     }
