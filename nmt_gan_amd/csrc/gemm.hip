@@ -647,10 +647,10 @@ struct GroupProb {
   const float* v0; const float* v1;             // CONVMAX / CONVADD: scale, shift; LINEAR: bias (may be null), unused
   const float* add; const int32_t* add_blk;     // CONVADD
   int64_t a_group_stride_b, ldw_b, ld_out, k_step, k_jump;
-  int M, N, nkt, a_group, lda_b, k_inner, ntn, add_rows, add_row0, relu;
+  int M, N, nkt, a_group, lda_b, k_inner, ntn, ntm, add_rows, add_row0, relu;
 };
 struct GroupParams {
-  int n_prob, n_tiles;
+  int n_prob, n_tiles, group_m;
   int tile_end[GROUP_MAX];                      // cumulative tile counts (ascending)
   GroupProb prob[GROUP_MAX];
 };
@@ -672,8 +672,23 @@ __global__ __launch_bounds__(512) void gemm_group_kernel(GroupParams gp) {
     const int first = qq > 0 ? gp.tile_end[qq - 1] : 0;
     const int ntn = gp.prob[qq].ntn;
     q = qq;
-    tm = (L - first) / ntn;
-    tn = (L - first) - tm * ntn;
+    // XCD-aware order inside the problem: workgroup b runs on XCD b & 7 and the grid is a multiple of 8 (or one tile
+    // per workgroup), so the problem's tiles with equal (L - first) & 7 share an XCD; they get one contiguous range of
+    // the problem's tiles, column tiles fastest - the column tiles of an A panel (up to 12.8 MB of window rows at
+    // w = 49) run side by side on ONE L2 instead of being fetched by five of them
+    const int n = gp.tile_end[qq] - first, i = L - first;
+    const int o = i & 7, qd = n >> 3, r = n & 7;
+    const int idx = (o < r ? o * (qd + 1) : r * (qd + 1) + (o - r) * qd) + (i >> 3);
+    // ... and inside the range, groups of group_m row tiles x all column tiles, row tile fastest: the ~32 tiles an
+    // XCD works on at a time are group_m A panels x ntn W tiles, so every W tile streamed from memory serves group_m
+    // workgroups (a problem's filter bank, up to 30 MB, does not stay in a 4 MB L2 between tiles)
+    const int ntm = gp.prob[qq].ntm, gm = gp.group_m;
+    const int gsize = gm * ntn;
+    const int first_m = (idx / gsize) * gm;
+    const int gsz = min(ntm - first_m, gm);
+    const int rem = idx - (idx / gsize) * gsize;
+    tm = first_m + rem % gsz;
+    tn = rem / gsz;
   };
 
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
@@ -1790,6 +1805,7 @@ int launch_gemm_group(const nmtgan_gemm_args* args, int n, hipStream_t st, int m
       q.a_group_stride_b = p.a_group_stride_b; q.ldw_b = p.ldw_b; q.k_step = p.k_step; q.k_jump = p.k_jump;
       q.M = p.M; q.N = p.N; q.nkt = p.kbytes / BKB; q.a_group = p.a_group; q.lda_b = (int)p.lda_b; q.k_inner = p.k_inner;
       q.ntn = (p.N + PBN - 1) / PBN;
+      q.ntm = (p.M + PBM - 1) / PBM;
       NMTGAN_REQUIRE(p.lda_b < (int64_t)1 << 31, "gemm_grouped: lda too large");
       if (epi == NMTGAN_EPI_LINEAR) {
         q.out = p.out[0]; q.ld_out = p.ldo[0]; q.v0 = p.bias; q.relu = p.relu;
@@ -1802,6 +1818,8 @@ int launch_gemm_group(const nmtgan_gemm_args* args, int n, hipStream_t st, int m
       gp.tile_end[i] = (int)tiles;
     }
     gp.n_tiles = (int)tiles;
+    static const int group_m = [] { const char* e = getenv("NMTGAN_GROUP_GM"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+    gp.group_m = group_m;
     prof::Scope prof_scope(prof::GEMM_PROJ, st);
     if (epi == NMTGAN_EPI_LINEAR) {
       NMTGAN_DISPATCH_OP(op, OpT, NMTGAN_TRY((launch_group<OpT, NMTGAN_EPI_LINEAR>(gp, st))));

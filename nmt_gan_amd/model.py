@@ -95,7 +95,7 @@ class Model(object):
         self._keep, self._c = [], None
         self._ws = None
         self.logits_chunk_rows = 4096
-        self.disc_chunk_rows = 8192
+        self.disc_chunk_rows = 4096    # rows per discriminator pass: one run of equal give_num / 4 at C2 (64 x 16 x 4 rows)
         # two-stream schedule of get_reward (discriminator scoring of finished rollouts overlaps the decode steps)
         self.overlap = True
         self.group_slots = True        # 32 // rollnum prefix groups of a sentence per attention workgroup

@@ -96,13 +96,14 @@ def test_fullsize_schedules_agree(c2):
     # follows the row's own give_num, so every score is the same under any batching
     assert np.array_equal(d1["p_rows"], c2["det"]["p_rows"])
     assert np.array_equal(r1, c2["r"])
-    for chunk in (3000, 20000):                              # other discriminator chunk sizes: same bits
+    default_chunk = m.disc_chunk_rows
+    for chunk in (3000, 8192, 20000):                        # other discriminator chunk sizes: same bits
         try:
             m.disc_chunk_rows = chunk
             rc = m.get_reward(c2["x"], c2["xp"], c2["y"], c2["mask"], R, c2["disc"], max_len=T, bias_num=0.6,
                               uniforms=c2["u"], return_details=True)
         finally:
-            m.disc_chunk_rows = 8192
+            m.disc_chunk_rows = default_chunk
         assert np.array_equal(m.last_details["p_rows"], c2["det"]["p_rows"]), chunk
         assert np.array_equal(rc, c2["r"])
     try:
