@@ -89,14 +89,17 @@ def algorithmic_work(cfg, plan, B, Ls, es):
     }
 
 
-PROFILE_TAG = {"fp16": "r2_c2_fp16", "bf16": "r1_c2_bf16", "fp16x3": "r2_c2_fp16x3"}     # committed PMC summaries under profiles/
+PROFILE_TAG = {"fp16": "r3_c2_fp16", "bf16": "r1_c2_bf16", "fp16x3": "r3_c2_fp16x3"}     # committed PMC summaries under profiles/
 # kernel classes -> kernels of the PMC summary (template argument 2 of the GEMM kernels is the epilogue; the element
 # type prints as `unsigned short` for bf16 and `_Float16` for fp16)
 TRAFFIC_KERNELS = {
-    "gemm_conv": r"gemm_\w+_kernel<(unsigned short|_Float16), 1[,>]",
+    # 1 = conv + max (single-problem kernels), 101 = the grouped kernel (conv + max with the table term of the
+    # partial-window reuse): together every conv product of the discriminator
+    "gemm_conv": r"gemm_\w+_kernel<(unsigned short|_Float16), (1|101)[,>]",
     "gemm_logits": r"gemm_\w+_kernel<(unsigned short|_Float16), (2|100)[,>]",     # 2 in the bf16 summary, made by an earlier build
     # (the split-precision tier's fp32 row kernel also serves its 24 encoder / prefill launches, 8 % of the launches)
-    "attn_self_private": r"attn_rows_(bf16|16)_kernel|attn_rows_kernel<float",
+    # the rollout steps' self-attention: one per-row launch over shared prefix + private suffix
+    "attn_self_step": r"attn_rows_(bf16|16)_kernel|attn_rows_kernel<float",
     "add_layernorm": r"addln_kernel",
     "sampler_rows": r"sample_kernel",
 }
@@ -501,8 +504,8 @@ def main():
                                       "call; a conv call split into 256-column panels + remainder shows as two kernels in "
                                       "rocprof, same total); traffic = HBM bytes per launch from the committed PMC summary "
                                       "profiles/" + PROFILE_TAG.get(args.precision, "none") + "_hbm_traffic.json (for gemm_conv: "
-                                      "the fused conv+max kernels only; the partial-window GEMMs share their kernel with the "
-                                      "decoder's); mfma_busy_frac = matrix-core busy cycles / elapsed cycles at the clock the "
+                                      "the single-problem conv+max kernels and the grouped kernel that runs the smaller and the "
+                                      "partial-window products); mfma_busy_frac = matrix-core busy cycles / elapsed cycles at the clock the "
                                       "kernels held (profiles/..._mfma_util.json)"}
         result["roofline_all"] = rows
         result["profiled_step_ms"] = round(profiled_ms, 2)
