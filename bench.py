@@ -435,7 +435,7 @@ def main():
         hm = tiers.get(args.precision, {}).get("meets_north_star")
         if hm is not None:
             result["value_meets_north_star"] = hm
-        # (names kept from earlier rounds)
+        # (flat field names that readers of earlier versions of this line look for)
         result["fp32_tier_ms_per_step"] = tiers["fp32"]["ms_per_step"]
         result["fp16x3_tier_ms_per_step"] = tiers["fp16x3"]["ms_per_step"]
         result["fp16x3_tier_sentences_per_s"] = tiers["fp16x3"]["sentences_per_s"]

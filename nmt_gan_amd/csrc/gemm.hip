@@ -593,7 +593,8 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmParams p) {
 static thread_local int g_wg_cap = 0;
 void set_gemm_wg_cap(int cap) { g_wg_cap = cap > 0 ? (cap + 7) / 8 * 8 : 0; }   // multiple of 8: one share per XCD
 static inline int persistent_grid(int nwg) {
-  const int cus = g_wg_cap > 0 && g_wg_cap < 256 ? g_wg_cap : 256;
+  const int cus = g_wg_cap > 0 ? g_wg_cap : 256;      // a cap above 256 = more workgroups than CUs: with one tile per
+                                                      // workgroup a CU is released after every tile
   return nwg < cus ? nwg : cus;
 }
 
