@@ -354,3 +354,23 @@ def test_two_rank_gloo_sharding_and_gather(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+
+
+def test_bench_tier_flags_come_from_the_tracked_accuracy_records():
+    """bench.py's `tiers` block reads the accuracy every tier was measured at from the records the repository tracks
+    (profiles/r3_precision_c2_<tier>_<vehicle>.json, written by tests/test_gpu_precision_c2.py on an MI355X): the
+    split-precision tier meets every clause of the stated tolerance on both vehicles, the fp16 tier the logits clause
+    only, and the worst vehicle decides."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    x3 = bench.tier_accuracy("fp16x3")
+    assert x3 is not None and set(x3["vehicles"]) == {"reference-init", "trained-like"}
+    assert x3["meets_north_star"] == {"logits": True, "tokens": True, "rewards": True, "all": True}
+    assert x3["logits_rel"] <= 1e-5 and x3["token_agreement"] >= 0.995 and x3["reward_rel"] <= 1e-3 and x3["p_real_abs"] <= 1e-3
+    f16 = bench.tier_accuracy("fp16")
+    assert f16["meets_north_star"]["logits"] and not f16["meets_north_star"]["tokens"] and not f16["meets_north_star"]["all"]
+    f32 = bench.tier_accuracy("fp32")
+    assert f32["tolerance"]["logits_rel"] == 1e-5 and f32["meets_north_star"]["logits"] and f32["meets_north_star"]["tokens"]
+    assert bench.tier_accuracy("no-such-tier") is None
