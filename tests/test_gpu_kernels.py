@@ -241,6 +241,51 @@ def test_gemm_grouped_equals_single_launches(cuda, op):
         assert torch.equal(single, out)
 
 
+def test_gemm_grouped_many_problems(cuda):
+    """More problems than one grouped launch holds (24): 31 conv products with random row counts, widths, window ranges
+    and filter counts - single tiles, ragged M and N, k-loops of 4 to 40 tiles - against one nmtgan_gemm call each."""
+    L = _lib()
+    rng = np.random.default_rng(5)
+    g = torch.Generator().manual_seed(9)
+    T, E, Fp = 24, 64, 768
+    e = (torch.rand(700, T, E, generator=g) * 2 - 1).half().to(cuda)
+    probs, singles, groupeds, keep = [], [], [], []
+    for i in range(31):
+        w = int(rng.integers(4, 21))
+        S = int(rng.choice([1, 3, 40, 129, 300, 700]))
+        n = int(rng.integers(1, 700))
+        p0 = int(rng.integers(0, T - w + 1))
+        P = int(rng.integers(1, T - w + 2 - p0))
+        Wt = (torch.randn(n, w * E, generator=g) * 0.1).half().to(cuda)
+        scale = (1 + 0.3 * torch.randn(n, generator=g)).to(cuda)
+        shift = (0.3 * torch.randn(n, generator=g)).to(cuda)
+        pair = []
+        for _ in range(2):
+            pooled = torch.zeros(S, Fp, device=cuda)
+            a = L.GemmArgs()
+            a.op_dtype, a.epilogue = L.NMTGAN_F16, L.EPI_CONVMAX
+            a.A, a.Wt = e.data_ptr() + p0 * E * 2, Wt.data_ptr()
+            a.M, a.N, a.K, a.lda, a.a_group, a.a_group_stride = S * P, n, w * E, E, P, T * E
+            a.scale, a.shift, a.pooled, a.ld_pool = scale.data_ptr(), shift.data_ptr(), pooled.data_ptr(), Fp
+            pair.append((a, pooled))
+        L.check(L.lib.nmtgan_gemm(C.byref(pair[0][0]), L.stream_ptr()), "gemm")
+        probs.append(pair[1][0])
+        singles.append(pair[0][1])
+        groupeds.append(pair[1][1])
+        keep.append((Wt, scale, shift))
+    arr = (L.GemmArgs * len(probs))(*probs)
+    L.check(L.lib.nmtgan_gemm_grouped(arr, len(probs), L.stream_ptr()), "gemm_grouped")
+    torch.cuda.synchronize()
+    for i, (a_, b_) in enumerate(zip(singles, groupeds)):
+        assert torch.equal(a_, b_), i
+    assert sum(float(x.abs().max()) > 0 for x in singles) >= 25
+    # argument errors are reported before anything is launched
+    bad = (L.GemmArgs * 2)(probs[0], probs[1])
+    bad[1].op_dtype = L.NMTGAN_F32
+    assert L.lib.nmtgan_gemm_grouped(bad, 2, L.stream_ptr()) != 0 and b"share op dtype" in L.lib.nmtgan_last_error()
+    assert L.lib.nmtgan_gemm_grouped(None, 0, L.stream_ptr()) == 0
+
+
 @pytest.mark.parametrize("d", [64, 128, 512, 1024])
 def test_add_layernorm(cuda, d):
     L = _lib()
