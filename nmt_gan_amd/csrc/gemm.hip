@@ -656,6 +656,8 @@ struct GroupParams {
   GroupProb prob[GROUP_MAX];
 };
 
+static_assert(sizeof(GroupParams) <= 4096, "the problem table travels as kernel arguments (4 KB)");
+
 template <typename OpT, int EPI>
 __global__ __launch_bounds__(512) void gemm_group_kernel(GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
