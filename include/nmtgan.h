@@ -410,6 +410,15 @@ typedef struct {
                                        blocks of this many taps, from one pass over y_sample and only multiplies the
                                        rest.  0 = default (4; 8 when NMTGAN_CONV_GROUP=0 launches every product on its
                                        own), < 0 = off (every such window is multiplied in full) */
+  int conv_table;                   /* table form of the target tower's conv for the rollouts (needs row_g_host): the call
+                                       first multiplies the WHOLE embedding table with every filter tap,
+                                       P_w[v][j][:] = E[v] . W_w[j] (workspace: vocab * sum_w w * n_w entries - fp32 for a
+                                       gemm_split or fp32 discriminator, else the op dtype), and a window of a rollout is
+                                       then w gathered rows of P added in tap order (its leading prefix taps come as one
+                                       partial sum from a pass over y_sample) - HBM-bound reads in place of the conv GEMMs,
+                                       which recompute every (token, tap) product ~ n_rows * T / vocab times.
+                                       0 = default (on when the tables fit conv_table_max_bytes), < 0 = off */
+  int64_t conv_table_max_bytes;     /* 0 = default (96 GiB) */
 } nmtgan_reward_plan;
 size_t nmtgan_rollout_reward_workspace_bytes(const nmtgan_generator* g, const nmtgan_discriminator* d,
                                              const nmtgan_reward_plan* plan);

@@ -117,7 +117,8 @@ class RewardPlan(C.Structure):
                 ("grp_first", vp), ("uniforms", vp), ("use_bias", i32), ("bias_num", f64),
                 ("logits_chunk_rows", i32), ("disc_chunk_rows", i32),
                 ("rewards", vp), ("rollouts", vp), ("p_rows", vp), ("p_base", vp), ("prefix_logits", vp),
-                ("row_g_host", vp), ("grp_table", vp), ("grp_slots", i32), ("grp_live", vp), ("aux_stream", vp), ("aux_gemm_wgs", i32), ("aux_min_rows", i32), ("conv_bucket_taps", i32)]
+                ("row_g_host", vp), ("grp_table", vp), ("grp_slots", i32), ("grp_live", vp), ("aux_stream", vp), ("aux_gemm_wgs", i32), ("aux_min_rows", i32), ("conv_bucket_taps", i32),
+                ("conv_table", i32), ("conv_table_max_bytes", i64)]
 
 
 EXPORTS = {

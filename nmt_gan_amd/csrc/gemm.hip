@@ -644,11 +644,11 @@ static int launch_pipe(GemmParams p, hipStream_t st) {
 constexpr int GROUP_MAX = 24;
 struct GroupProb {
   const char* A; const char* W;
-  void* out;                                    // CONVMAX / CONVADD: pooled features; LINEAR: fp32 output
+  void* out;                                    // CONVMAX / CONVADD: pooled features; LINEAR: output (fp32 or op dtype)
   const float* v0; const float* v1;             // CONVMAX / CONVADD: scale, shift; LINEAR: bias (may be null), unused
   const float* add; const int32_t* add_blk;     // CONVADD
   int64_t a_group_stride_b, ldw_b, ld_out, k_step, k_jump;
-  int M, N, nkt, a_group, lda_b, k_inner, ntn, ntm, add_rows, add_row0, relu;
+  int M, N, nkt, a_group, lda_b, k_inner, ntn, ntm, add_rows, add_row0, relu, omode;
 };
 struct GroupParams {
   int n_prob, n_tiles, group_m;
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(512) void gemm_group_kernel(GroupParams gp) {
     v.M = pr.M; v.N = pr.N; v.a_group = pr.a_group;
     if constexpr (EPI == NMTGAN_EPI_LINEAR) {
       v.bias = pr.v0; v.relu = pr.relu; v.n_seg = 1; v.seg_width = pr.N;
-      v.out[0] = pr.out; v.ldo[0] = pr.ld_out; v.out_f32[0] = 1; v.seg_scale[0] = 1.f;
+      v.out[0] = pr.out; v.ldo[0] = pr.ld_out; v.out_f32[0] = pr.omode; v.seg_scale[0] = 1.f;
     } else {
       v.scale = pr.v0; v.shift = pr.v1; v.pooled = reinterpret_cast<float*>(pr.out); v.ld_pool = pr.ld_out;
       v.add = pr.add; v.add_blk = pr.add_blk; v.add_rows = pr.add_rows; v.add_row0 = pr.add_row0;
@@ -1769,7 +1769,7 @@ static int launch_gemm_impl(const nmtgan_gemm_args* a, hipStream_t st) {
 }
 
 // Several independent GEMMs of one epilogue kind (CONVMAX, with or without the additive term, or LINEAR with a single
-// fp32 output segment) in as few persistent launches as their count needs (GROUP_MAX problems each), longest k-loop
+// output segment, fp32 or op dtype) in as few persistent launches as their count needs (GROUP_MAX problems each), longest k-loop
 // first.  A problem the grouped kernel does not take (k extent not a multiple of 128 bytes, fewer than 4 k-tiles)
 // is launched on its own.  min_tiles > 0: problems with at least that many 256x128 tiles are launched on their own too
 // (the 256x256 kernel serves them better), unless they carry the additive term.
@@ -1787,7 +1787,7 @@ int launch_gemm_group(const nmtgan_gemm_args* args, int n, hipStream_t st, int m
     NMTGAN_TRY(fill_params(&a, p));
     if (a.M == 0) continue;
     const bool fits = p.kbytes % BKB == 0 && p.kbytes / BKB >= 4;
-    const bool lin_ok = epi != NMTGAN_EPI_LINEAR || (a.n_seg == 1 && a.out_f32[0] == 1 && a.seg_scale[0] == 1.f);
+    const bool lin_ok = epi != NMTGAN_EPI_LINEAR || (a.n_seg == 1 && a.out_f32[0] != 2 && a.seg_scale[0] == 1.f);
     const int64_t tiles = (int64_t)((p.M + PBM - 1) / PBM) * ((p.N + PBN - 1) / PBN);
     if (!fits || !lin_ok || (min_tiles > 0 && tiles >= min_tiles && !p.add)) {
       NMTGAN_REQUIRE(!p.add, "gemm: the additive CONVMAX form needs K*esize %% 128 == 0 and >= 4 k-tiles");
@@ -1811,7 +1811,7 @@ int launch_gemm_group(const nmtgan_gemm_args* args, int n, hipStream_t st, int m
       q.ntm = (p.M + PBM - 1) / PBM;
       NMTGAN_REQUIRE(p.lda_b < (int64_t)1 << 31, "gemm_grouped: lda too large");
       if (epi == NMTGAN_EPI_LINEAR) {
-        q.out = p.out[0]; q.ld_out = p.ldo[0]; q.v0 = p.bias; q.relu = p.relu;
+        q.out = p.out[0]; q.ld_out = p.ldo[0]; q.v0 = p.bias; q.relu = p.relu; q.omode = p.out_f32[0];
       } else {
         q.out = p.pooled; q.ld_out = p.ld_pool; q.v0 = p.scale; q.v1 = p.shift;
         q.add = p.add; q.add_blk = p.add_blk; q.add_rows = p.add_rows; q.add_row0 = p.add_row0;

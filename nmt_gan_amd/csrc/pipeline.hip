@@ -404,9 +404,10 @@ static int bucket_delta(const nmtgan_reward_plan* p) {          // NMTGAN_CONV_B
 // highway features of `rows` sentences ids[rows][T] -> feat[rows][Fp]
 static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* ids,
                                int rows, float* feat, DiscBufs& b, hipStream_t st, const PrefixReuse* reuse = nullptr,
-                               const BucketReuse* bk = nullptr) {
+                               const BucketReuse* bk = nullptr, const ConvTable* table = nullptr) {
   const int T = d->max_len, E = disc_ew(d), Fp = d->Fp, op = d->op_dtype;
-  NMTGAN_TRY(launch_disc_embed(tw.emb, op, &tw == &d->src ? d->vocab_s : d->vocab, ids, (int64_t)rows * T, E, b.e, st));
+  if (table) NMTGAN_REQUIRE(reuse != nullptr, "disc: the table form scores rollouts (needs their give points)");
+  else NMTGAN_TRY(launch_disc_embed(tw.emb, op, &tw == &d->src ? d->vocab_s : d->vocab, ids, (int64_t)rows * T, E, b.e, st));
   if (reuse) {
     NMTGAN_TRY(launch_pool_init(reuse->pm, reuse->row_b, reuse->row_g, rows, T, Fp, b.pooled, st));
   } else {
@@ -427,8 +428,13 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
     prof::Hint ph(prof::GEMM_CONV);
     return launch_gemm(&a, st);
   };
+  if (table) {
+    // every window that holds a sampled token, as gathered rows of the per-(token, tap) tables
+    prof::Hint ph(prof::GEMM_CONV);
+    NMTGAN_TRY(launch_table_conv(*table, ids, reuse->row_b, reuse->row_g, rows, b.pooled, st));
+  }
   int col = 0;
-  for (int i = 0; i < d->n_widths; ++i) {
+  for (int i = 0; i < (table ? 0 : d->n_widths); ++i) {
     const int w = d->widths[i];
     const bool buckets = reuse && bk && bk->delta > 0 && w > bk->delta;
     // sub-ranges of at most REUSE_ROWS rows.  Windows every row of a sub-range shares with y_sample are skipped:
@@ -560,6 +566,40 @@ static int bucket_tables(const nmtgan_discriminator* d, const nmtgan_disc_tower&
   return 0;
 }
 
+// Table form of the target tower's conv for the rollouts (disc_table.hip): P_w[v][j][:] = E[v] . W_w[j] for the whole
+// vocabulary, one GEMM problem per (width, tap) over the embedding table (M = vocab, K = one token's operand row,
+// N = n_filters, output row stride w * nfp), in grouped persistent launches.  Split-precision operands give an fp32
+// table, 16-bit operands a table of their own type, fp32 operands an fp32 table.
+static int conv_table_dtype(const nmtgan_discriminator* d) { return d->gemm_split ? NMTGAN_F32 : d->op_dtype; }
+static int conv_table_nfp(const nmtgan_discriminator* d, int nf) {        // table rows padded to whole 128-byte lines
+  const int per = 128 / dtype_size(conv_table_dtype(d));
+  return (nf + per - 1) / per * per;
+}
+static int64_t conv_table_bytes(const nmtgan_discriminator* d) {
+  int64_t n = 0;
+  for (int i = 0; i < d->n_widths; ++i)
+    n += align_up((size_t)d->vocab * d->widths[i] * conv_table_nfp(d, d->n_filters[i]) * dtype_size(conv_table_dtype(d)), 256);
+  return n;
+}
+static int build_conv_table(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const ConvTable& t, hipStream_t st) {
+  const int E = disc_ew(d), op = d->op_dtype, es = dtype_size(op), tes = dtype_size(t.dtype);
+  std::vector<nmtgan_gemm_args> probs;
+  for (int i = 0; i < d->n_widths; ++i) {
+    const int w = d->widths[i];
+    for (int j = 0; j < w; ++j) {
+      nmtgan_gemm_args a{};
+      a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
+      a.A = tw.emb; a.lda = E; a.M = d->vocab; a.K = E; a.N = d->n_filters[i];
+      a.Wt = at(tw.conv_w[i], (int64_t)j * E, es); a.ldw = (int64_t)w * E;
+      a.n_seg = 1; a.seg_width = a.N; a.out[0] = at(t.tab[i], (int64_t)j * t.nfp[i], tes); a.ldo[0] = (int64_t)w * t.nfp[i];
+      a.out_f32[0] = t.dtype == NMTGAN_F32 ? 1 : 0; a.seg_scale[0] = 1.f;
+      probs.push_back(a);
+    }
+  }
+  prof::Hint ph(prof::GEMM_CONV);
+  return launch_gemm_group(probs.data(), (int)probs.size(), st, 0);
+}
+
 // C[b*T + p][Fp] = relu(bn(conv)) of every window p of rows sentences (one "sentence" of rows*T tokens with
 // a pooling group of one window; windows that run over a sentence end are computed and never read)
 static int disc_window_values(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* ids, int rows,
@@ -647,6 +687,7 @@ struct RewardBufs {
   float *feat_s, *feat_t, *p_rows, *p_base;
   float *win_vals, *win_pm; bool reuse;        // prefix-window reuse in the discriminator
   BucketReuse bucket;                          // partial-window reuse (delta = 0: off)
+  ConvTable table; bool use_table;             // table form of the rollouts' conv (replaces the two above's GEMMs)
   DiscBufs disc;
   int64_t act_rows, logits_rows, pr_rows;
   int disc_chunk;
@@ -717,6 +758,22 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
     b.win_vals = ar.get<float>(wrows * d->Fp);
     b.win_pm = ar.get<float>((int64_t)p->B * p->T * d->Fp);
   }
+  // table form: on by default (NMTGAN_CONV_TABLE=0 or plan.conv_table < 0 switch it off) when the tables fit the cap
+  static const bool table_env = [] { const char* e = getenv("NMTGAN_CONV_TABLE"); return !e || atoi(e) != 0; }();
+  const int64_t table_cap = p->conv_table_max_bytes > 0 ? p->conv_table_max_bytes : (int64_t)96 << 30;
+  b.table = ConvTable{};
+  b.use_table = table_env && p->conv_table >= 0 && b.reuse && p->T <= TABLE_MAX_LEN && conv_table_bytes(d) <= table_cap;
+  if (b.use_table) {
+    ConvTable& t = b.table;
+    t.n_widths = d->n_widths; t.T = p->T; t.Fp = d->Fp; t.vocab = d->vocab; t.dtype = conv_table_dtype(d);
+    for (int i = 0; i < d->n_widths; ++i) {
+      const int w = d->widths[i];
+      t.w[i] = w; t.nf[i] = d->n_filters[i]; t.nfp[i] = conv_table_nfp(d, d->n_filters[i]);
+      t.scale[i] = d->tgt.conv_scale[i]; t.shift[i] = d->tgt.conv_shift[i];
+      t.tab[i] = ar.take((size_t)d->vocab * w * t.nfp[i] * dtype_size(t.dtype));
+      t.S[i] = ar.get<float>((size_t)p->B * (p->T - w + 1) * (w > 1 ? w - 1 : 1) * t.nfp[i]);
+    }
+  }
   b.bucket = BucketReuse{};
   int max_w = 0, max_n = 0;
   for (int i = 0; i < d->n_widths; ++i) {
@@ -725,7 +782,7 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   }
   const int dl = bucket_delta(p);
   const int des = dtype_size(d->op_dtype);
-  if (b.reuse && dl > 0 && (d->dim_word * des) % 128 == 0 && (max_w - 1) / dl < BUCKET_MAX_C && max_w > dl) {
+  if (b.reuse && !b.use_table && dl > 0 && (d->dim_word * des) % 128 == 0 && (max_w - 1) / dl < BUCKET_MAX_C && max_w > dl) {
     b.bucket.delta = dl;
     b.bucket.ye = ar.take((size_t)p->B * p->T * disc_ew(d) * des);
     int64_t off = 0;
@@ -832,9 +889,15 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
       NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s + (int64_t)r0 * d->Fp, nullptr, rows, d->Fp, d->head_w, d->head_b,
                                   b.p_base + r0, nullptr, ds));
     }
+    if (b.use_table) NMTGAN_TRY(build_conv_table(d, d->tgt, b.table, ds));
     if (b.reuse) {
       for (int r0 = 0; r0 < B; r0 += b.disc_chunk) {
         const int rows = B - r0 < b.disc_chunk ? B - r0 : b.disc_chunk;
+        if (b.use_table) {
+          ConvTable t = b.table;                  // the chunk's slice of the partial sums
+          for (int i = 0; i < t.n_widths; ++i) t.S[i] += (int64_t)r0 * (T - t.w[i] + 1) * (t.w[i] - 1) * t.nfp[i];
+          NMTGAN_TRY(launch_table_prefix(t, p->y + (int64_t)r0 * T, rows, b.win_vals, ds));
+        } else
         NMTGAN_TRY(disc_window_values(d, d->tgt, p->y + (int64_t)r0 * T, rows, b.win_vals, b.disc, ds));
         NMTGAN_TRY(launch_prefix_max(b.win_vals, b.win_pm + (int64_t)r0 * T * d->Fp, rows, T, d->Fp, d->n_widths,
                                      d->widths, d->n_filters, ds));
@@ -858,7 +921,7 @@ int rollout_reward(const nmtgan_generator* g, const nmtgan_discriminator* d, con
       }
       PrefixReuse pr{b.win_pm, p->row_b + r0, p->row_g + r0, b.reuse ? p->row_g_host + r0 : nullptr};
       NMTGAN_TRY(disc_features_chunk(d, d->tgt, b.Y + (int64_t)r0 * T, rows, b.feat_t, b.disc, ds, b.reuse ? &pr : nullptr,
-                                     b.reuse && b.bucket.delta > 0 ? &b.bucket : nullptr));
+                                     b.reuse && b.bucket.delta > 0 ? &b.bucket : nullptr, b.use_table ? &b.table : nullptr));
       NMTGAN_TRY(launch_disc_head(b.feat_t, b.feat_s, p->row_b + r0, rows, d->Fp, d->head_w, d->head_b, b.p_rows + r0,
                                   nullptr, ds));
     }

@@ -100,6 +100,9 @@ class Model(object):
         self.overlap = True
         self.group_slots = True        # 32 // rollnum prefix groups of a sentence per attention workgroup
         self.conv_bucket_taps = 0      # partial-window reuse in the discriminator: 0 = library default, < 0 off
+        self.conv_table = 0            # table form of the rollouts' conv (per-(token, tap) filter responses of the whole
+        #                                vocabulary, rebuilt inside every get_reward): 0 = library default (on), < 0 off
+        self.conv_table_max_bytes = 0  # 0 = library default (96 GiB of workspace for the tables)
         self.aux_gemm_wgs = 0          # 0 = library default
         self.aux_min_rows = 0
         self._aux_stream = None
@@ -659,6 +662,7 @@ class Model(object):
         p.disc_chunk_rows = self.disc_chunk_rows
         p.rewards = ptr(t["rewards"])
         p.conv_bucket_taps = int(self.conv_bucket_taps)
+        p.conv_table, p.conv_table_max_bytes = int(self.conv_table), int(self.conv_table_max_bytes)
         if "grp_table" in t:
             p.grp_table, p.grp_slots, p.grp_live = ptr(t["grp_table"]), int(plan.grp_slots), grp_live.ctypes.data
         if self.overlap:
