@@ -47,8 +47,22 @@ class Cfg(dict):
     __getattr__ = dict.get
 
 
-def algorithmic_work(cfg, plan, B, Ls, es):
-    """Algorithmic FLOPs / bytes per kernel class for ONE get_reward."""
+def table_gather_bytes(T, widths, nf, row_g, tes):
+    """Bytes the table form of the rollouts' conv has to read for ONE get_reward: for a rollout with give point g and a
+    filter of width w, every window q >= g - w + 1 adds its w - max(0, g - q) own taps (rows of n_w table entries of
+    `tes` bytes) to one fp32 partial-sum row taken from the pass over y_sample when the window starts inside the prefix."""
+    per_g = np.zeros(T + 1, np.int64)
+    for g in range(1, T):
+        for w, n in zip(widths, nf):
+            q = np.arange(max(0, g - w + 1), T - w + 1)
+            pre = np.maximum(0, g - q)
+            per_g[g] += int(((w - pre) * n * tes + (pre > 0) * n * 4).sum())
+    return int(per_g[np.asarray(row_g, np.int64)].sum())
+
+
+def algorithmic_work(cfg, plan, B, Ls, es, table_es=0):
+    """Algorithmic FLOPs / bytes per kernel class for ONE get_reward (table_es > 0: the rollouts' conv runs in its
+    table form with entries of that many bytes)."""
     d, N, T, V, E, R = cfg["d"], cfg["blocks"], cfg["T"], cfg["V"], cfg["E"], cfg["rollnum"]
     live = plan.live.astype(np.int64)
     step_rows = int(live[1:].sum())
@@ -70,11 +84,18 @@ def algorithmic_work(cfg, plan, B, Ls, es):
         self_entries += int((g_of_group[alive] + 1).sum()) + int(alive.sum()) * R * s
         priv_entries += int(alive.sum()) * R * s
     cross_entries = sum(int(np.unique(plan.row_b[:live[s]]).size) * Ls for s in range(1, plan.n_steps + 1))
+    conv_flops = conv_per_row * scored
+    extra = {}
+    if table_es:
+        # the GEMMs left in the class: the per-(token, tap) tables of the whole vocabulary + y_sample and source towers
+        conv_flops = 2 * V * E * sum(w * n for w, n in zip(widths, nf)) + conv_per_row * 2 * B
+        extra["conv_table"] = ("hbm", table_gather_bytes(T, widths, nf, plan.row_g, table_es))
     return {
+        **extra,
         "gemm_proj": ("mfma", (12 * d * d * N) * dec_rows + (8 * d * d * N + 4 * d * d * N) * enc_rows),
         "gemm_ffn": ("mfma", (16 * d * d * N) * (dec_rows + enc_rows)),
         "gemm_logits": ("mfma", 2 * d * V * dec_rows),
-        "gemm_conv": ("mfma", conv_per_row * scored),
+        "gemm_conv": ("mfma", conv_flops),
         "gemm_highway": ("mfma", 4 * F * F * scored),
         # first token of every rollout: nmtgan_sample_rows over a prefix-logits row (the contract's 4V + 8 bytes per
         # sampled token; the rollnum rollouts of a prefix share the row, so all but 1/rollnum of it comes from L2)
@@ -102,6 +123,7 @@ TRAFFIC_KERNELS = {
     "attn_self_step": r"attn_rows_(bf16|16)_kernel|attn_rows_kernel<float",
     "add_layernorm": r"addln_kernel",
     "sampler_rows": r"sample_kernel",
+    "conv_table": r"table_conv_kernel",
 }
 
 
@@ -263,6 +285,9 @@ def main():
                     help="N > 1 rehearsal on a box with fewer GPUs than ranks: gloo backend, ranks share the visible GPUs "
                          "(device = local_rank %% device_count).  Exercises the sharding / gather / timing code of the "
                          "multi-GPU run; the JSON line is marked \"rehearsal\": true and is not a measurement")
+    ap.add_argument("--conv-table", type=int, default=0, choices=[-1, 0, 1],
+                    help="table form of the rollouts' discriminator conv: 0 library default (on for the 16-bit and split "
+                         "tiers; the tables are rebuilt inside every step), 1 on for every tier, -1 off (conv GEMMs)")
     ap.add_argument("--aux-wgs", type=int, default=0)
     ap.add_argument("--aux-min-rows", type=int, default=0)
     args = ap.parse_args()
@@ -312,6 +337,9 @@ def main():
         model.disc_chunk_rows = args.disc_chunk
     model.overlap = bool(args.overlap)
     model.aux_gemm_wgs, model.aux_min_rows = args.aux_wgs, args.aux_min_rows
+    model.conv_table = args.conv_table
+    table_on = os.environ.get("NMTGAN_CONV_TABLE") != "0" and (args.conv_table > 0 or
+                                                               (args.conv_table == 0 and args.precision != "fp32"))
 
     x, y = synthetic.synthetic_batch(Bg, T, V, V, seed=1234)         # no </S>: every row full length T
     y, mask = N.deal_generated_samples(y)
@@ -372,6 +400,9 @@ def main():
                    "sampled_tokens_per_step": int(prep.plan.n_rows + prep.plan.live[1:].sum()) * world,
                    "parallelism": "sentence-sharded x%d, RCCL all-gather of rewards" % world if world > 1 else "single GPU",
                    "workspace_GiB": round(prep.workspace_bytes / 2 ** 30, 2),
+                   "disc_conv": "table form: per-(token, tap) filter responses of the whole vocabulary rebuilt inside every "
+                                "step (the discriminator changes between get_reward calls in gan_train.py), windows of the "
+                                "rollouts gathered from them" if table_on else "conv GEMMs",
                    "schedule": "two-stream: discriminator scoring of finished rollouts overlaps the remaining decode "
                                "steps" if args.overlap else "single stream"},
     }
@@ -396,7 +427,7 @@ def main():
             mt = N.Model(mcfg, precision=precision, device=str(dev))
             mt.build_rollout_generate(T)
             mt.init_and_restore(weights=Wg)
-            mt.overlap = model.overlap
+            mt.overlap, mt.conv_table = model.overlap, model.conv_table
             dt = N.DisCNN(None, T, 2, V, Bl, cfg["E"], widths, nfs, vocab_size_s=V, precision=precision, device=str(dev))
             dt.load_weights(Wd)
             pt = mt.prepare_reward(x[b0:b1], xp[b0:b1], y[b0:b1], mask[b0:b1], R, dt, T, 0.6, u, b_offset=b0, B_global=Bg)
@@ -450,7 +481,8 @@ def main():
         _lib.lib.nmtgan_profile_start()
         prof_prep.launch()
         _lib.check(_lib.lib.nmtgan_profile_stop(ms, cnt, ncls), "profile_stop")
-        work = algorithmic_work(cfg, prep.plan, Bl, x.shape[1], 4 if args.precision in ("fp32", "fp16x3") else 2)
+        table_es = 0 if not table_on else (2 if args.precision in ("fp16", "bf16") else 4)
+        work = algorithmic_work(cfg, prep.plan, Bl, x.shape[1], 4 if args.precision in ("fp32", "fp16x3") else 2, table_es)
         rows = {}
         names = list(_lib.PROFILE_CLASSES)
         i_self, i_priv = names.index("attn_self_step"), names.index("attn_self_private")

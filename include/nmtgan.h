@@ -417,7 +417,9 @@ typedef struct {
                                        then w gathered rows of P added in tap order (its leading prefix taps come as one
                                        partial sum from a pass over y_sample) - HBM-bound reads in place of the conv GEMMs,
                                        which recompute every (token, tap) product ~ n_rows * T / vocab times.
-                                       0 = default (on when the tables fit conv_table_max_bytes), < 0 = off */
+                                       0 = default (on for a 16-bit or gemm_split discriminator when the tables fit
+                                       conv_table_max_bytes; an fp32 discriminator keeps the GEMM form), > 0 = on for
+                                       every op dtype (still subject to the size cap), < 0 = off */
   int64_t conv_table_max_bytes;     /* 0 = default (96 GiB) */
 } nmtgan_reward_plan;
 size_t nmtgan_rollout_reward_workspace_bytes(const nmtgan_generator* g, const nmtgan_discriminator* d,
@@ -539,8 +541,9 @@ int nmtgan_clip_values(float* w, int64_t n, float lo, float hi, void* w_op, int 
  * 12 disc_small (gather/cast/gate/head/reduce), 13 attn_self_private (the per-row pass over the private
  * suffix keys of a rollout step when the shared prefix went through nmtgan_attn_group; class 6 then holds
  * only the shared-prefix pass), 14 sampler_rows (nmtgan_sample_rows over materialised logits: the first token of
- * every rollout; class 9 then holds the fused logits+sampling tail of the rollout steps).  Allocates events: never
- * use inside timed runs.
+ * every rollout; class 9 then holds the fused logits+sampling tail of the rollout steps), 15 conv_table (the gathers
+ * of the table form of the rollouts' conv + max; class 4 then holds the GEMMs that build the tables and the conv of
+ * y_sample and of the source sentences).  Allocates events: never use inside timed runs.
  */
 int nmtgan_profile_classes(void);
 int nmtgan_profile_start(void);

@@ -167,7 +167,7 @@ EXPORTS = {
 
 PROFILE_CLASSES = ["other", "gemm_proj", "gemm_ffn", "gemm_logits", "gemm_conv", "gemm_highway", "attn_self_step",
                    "attn_cross_step", "attn_prefill", "sampler", "add_layernorm", "embed", "disc_small",
-                   "attn_self_private", "sampler_rows"]
+                   "attn_self_private", "sampler_rows", "conv_table"]
 
 
 class NmtGanError(RuntimeError):

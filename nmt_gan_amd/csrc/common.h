@@ -35,7 +35,7 @@ void set_error(const char* fmt, ...);
 namespace prof {
 enum Cls {
   OTHER = 0, GEMM_PROJ, GEMM_FFN, GEMM_LOGITS, GEMM_CONV, GEMM_HIGHWAY, ATTN_SELF, ATTN_CROSS, ATTN_PREFILL,
-  SAMPLER, ADDLN, EMBED, DISC_SMALL, ATTN_SELF_PRIVATE, SAMPLER_ROWS, N_CLS
+  SAMPLER, ADDLN, EMBED, DISC_SMALL, ATTN_SELF_PRIVATE, SAMPLER_ROWS, CONV_TABLE, N_CLS
 };
 extern bool g_on;
 extern thread_local int g_hint;          // class of the next launches, set by the pipelines

@@ -8,9 +8,9 @@
 // gathered rows of P added in tap order - HBM-bound reads of contiguous n_f-wide rows instead of 2*w*E*n_f flops.
 // A rollout (b, g) shares tokens 0..g-1 with y_sample[b]: windows that end inside the prefix come from the prefix-max
 // table as before, and a window that straddles the give point starts from S_w[b][p][g-p] = the sum of its first g-p
-// taps over y_sample (cumulative over taps, written once per call by table_prefix_kernel).  Taps are always added in
-// the order 0, 1, .., w-1 with the same fp32 adds whether a partial sum comes from S or is rebuilt, so a row's features
-// do not depend on what it shares, on the chunking or on the schedule.
+// taps over y_sample (cumulative over taps, written once per call by table_prefix_kernel).  Which terms of a window
+// come from S and which are gathered follows from the row's own give point alone, and the taps are added in the order
+// 0, 1, .., w-1, so a row's features do not depend on the chunking, the schedule or the sharding.
 #include "kernels.h"
 
 namespace nmtgan {
@@ -31,15 +31,19 @@ struct TableParams {
 };
 static_assert(sizeof(TableParams) <= 4096, "the width table travels as kernel arguments");
 
-template <typename TT> struct Row { static constexpr int VN = 16 / sizeof(TT); };
+// Taps of an fp32 table are added in fp64 (the kernels wait on memory, the adds are free): what is left of the
+// reference's fp32 conv sum is then the rounding of the table entries themselves, not the order of 2..49 adds at
+// |sum| ~ 100.  16-bit tables add in fp32, far below their entries' own rounding.
+template <typename TT> struct Row { static constexpr int VN = 16 / sizeof(TT); using Acc = float; };
+template <> struct Row<float> { static constexpr int VN = 4; using Acc = double; };
 
 // a[0..VN) += the VN table entries at p
-template <typename TT, int VN>
-__device__ __forceinline__ void add_row(float (&a)[VN], const TT* p) {
+template <typename TT, int VN, typename Acc>
+__device__ __forceinline__ void add_row(Acc (&a)[VN], const TT* p) {
   float v[VN];
   VecIO<TT, VN>::load(p, v);
 #pragma unroll
-  for (int k = 0; k < VN; ++k) a[k] += v[k];
+  for (int k = 0; k < VN; ++k) a[k] += (Acc)v[k];
 }
 
 // y_sample: block (p, b, i) adds the taps of window p of sentence b for width i in order, writes the partial sums
@@ -55,18 +59,24 @@ __global__ __launch_bounds__(128) void table_prefix_kernel(TableParams p) {
   __syncthreads();
   const TT* tab = reinterpret_cast<const TT*>(p.tab[i]);
   float* S = p.S[i] + ((int64_t)b * Pw + q) * (w - 1) * nfp;
+  using Acc = typename Row<TT>::Acc;
   for (int c = threadIdx.x * VN; c < nfp; c += blockDim.x * VN) {
-    float a[VN];
+    Acc a[VN];
 #pragma unroll
-    for (int k = 0; k < VN; ++k) a[k] = 0.f;
+    for (int k = 0; k < VN; ++k) a[k] = 0;
     for (int j = 0; j < w; ++j) {
-      add_row<TT, VN>(a, tab + ((int64_t)tok[j] * w + j) * nfp + c);
-      if (j + 1 < w) VecIO<float, VN>::store(S + (int64_t)j * nfp + c, a);
+      add_row<TT, VN, Acc>(a, tab + ((int64_t)tok[j] * w + j) * nfp + c);
+      if (j + 1 < w) {
+        float r[VN];
+#pragma unroll
+        for (int k = 0; k < VN; ++k) r[k] = (float)a[k];
+        VecIO<float, VN>::store(S + (int64_t)j * nfp + c, r);
+      }
     }
 #pragma unroll
     for (int k = 0; k < VN; ++k)
       if (c + k < p.nf[i])
-        p.out[((int64_t)b * T + q) * p.Fp + p.col[i] + c + k] = fmaxf(a[k] * p.scale[i][c + k] + p.shift[i][c + k], 0.f);
+        p.out[((int64_t)b * T + q) * p.Fp + p.col[i] + c + k] = fmaxf((float)a[k] * p.scale[i][c + k] + p.shift[i][c + k], 0.f);
   }
 }
 
@@ -75,6 +85,7 @@ __global__ __launch_bounds__(128) void table_prefix_kernel(TableParams p) {
 template <typename TT>
 __global__ __launch_bounds__(256) void table_conv_kernel(TableParams p) {
   constexpr int VN = Row<TT>::VN;
+  using Acc = typename Row<TT>::Acc;
   __shared__ int32_t tok[TABLE_MAX_LEN];
   __shared__ float red[256 * VN];
   const int i = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
@@ -100,19 +111,22 @@ __global__ __launch_bounds__(256) void table_conv_kernel(TableParams p) {
     }
     if (slot < G) {
       for (int q = q_lo + slot; q < Pw; q += G) {
-        float a[VN];
+        Acc a[VN];
         int j0 = 0;
         if (g > q) {
           j0 = g - q;                            // 1 .. w-1 taps of the prefix
-          VecIO<float, VN>::load(S + ((int64_t)q * (w - 1) + (j0 - 1)) * nfp + c, a);
+          float r[VN];
+          VecIO<float, VN>::load(S + ((int64_t)q * (w - 1) + (j0 - 1)) * nfp + c, r);
+#pragma unroll
+          for (int k = 0; k < VN; ++k) a[k] = (Acc)r[k];
         } else {
 #pragma unroll
-          for (int k = 0; k < VN; ++k) a[k] = 0.f;
+          for (int k = 0; k < VN; ++k) a[k] = 0;
         }
 #pragma unroll 8
-        for (int j = j0; j < w; ++j) add_row<TT, VN>(a, tab + ((int64_t)tok[q + j] * w + j) * nfp + c);
+        for (int j = j0; j < w; ++j) add_row<TT, VN, Acc>(a, tab + ((int64_t)tok[q + j] * w + j) * nfp + c);
 #pragma unroll
-        for (int k = 0; k < VN; ++k) m[k] = fmaxf(m[k], a[k] * sc[k] + sh[k]);
+        for (int k = 0; k < VN; ++k) m[k] = fmaxf(m[k], (float)a[k] * sc[k] + sh[k]);
       }
     }
     if (G > 1) {
@@ -132,6 +146,20 @@ __global__ __launch_bounds__(256) void table_conv_kernel(TableParams p) {
         if (c + k < p.nf[i]) o[k] = fmaxf(o[k], m[k]);
     }
   }
+}
+
+// filter bank Wt[nf][w][row_bytes] (one operand row per tap) -> tap-major rows out[j * nfp + f][row_bytes], rows
+// f >= nf zero: the W operand of ONE GEMM per width whose output row is a token's whole table entry [w][nfp]
+__global__ __launch_bounds__(256) void table_weights_kernel(const char* wt, int w, int nf, int nfp, int row_bytes, char* out) {
+  const int cpr = row_bytes >> 4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)w * nfp * cpr) return;
+  const int c = (int)(idx % cpr);
+  const int64_t row = idx / cpr;
+  const int j = (int)(row / nfp), f = (int)(row % nfp);
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (f < nf) v = reinterpret_cast<const uint4*>(wt + ((int64_t)f * w + j) * row_bytes)[c];
+  reinterpret_cast<uint4*>(out + row * row_bytes)[c] = v;
 }
 
 int fill(const ConvTable& t, TableParams& p) {
@@ -155,8 +183,18 @@ int fill(const ConvTable& t, TableParams& p) {
 
 }  // namespace
 
+int launch_table_weights(const void* wt, int w, int nf, int nfp, int row_bytes, void* out, hipStream_t st) {
+  prof::Scope prof_scope(prof::DISC_SMALL, st);
+  NMTGAN_REQUIRE(wt && out && w > 0 && nf > 0 && nfp >= nf && row_bytes > 0 && row_bytes % 16 == 0, "table_weights: bad arguments");
+  const int64_t n = (int64_t)w * nfp * (row_bytes >> 4);
+  hipLaunchKernelGGL(table_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const char*)wt, w, nf, nfp,
+                     row_bytes, (char*)out);
+  NMTGAN_CHECK_LAUNCH("table_weights");
+  return 0;
+}
+
 int launch_table_prefix(const ConvTable& t, const int32_t* y, int B, float* win_vals, hipStream_t st) {
-  prof::Scope prof_scope(prof::GEMM_CONV, st);
+  prof::Scope prof_scope(prof::CONV_TABLE, st);
   if (B == 0) return 0;
   TableParams p{};
   NMTGAN_TRY(fill(t, p));
@@ -170,7 +208,7 @@ int launch_table_prefix(const ConvTable& t, const int32_t* y, int B, float* win_
 
 int launch_table_conv(const ConvTable& t, const int32_t* ids, const int32_t* row_b, const int32_t* row_g, int rows,
                       float* pooled, hipStream_t st) {
-  prof::Scope prof_scope(prof::GEMM_CONV, st);
+  prof::Scope prof_scope(prof::CONV_TABLE, st);
   if (rows == 0) return 0;
   TableParams p{};
   NMTGAN_TRY(fill(t, p));

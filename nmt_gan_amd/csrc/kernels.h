@@ -67,7 +67,10 @@ struct ConvTable {
   void* tab[NMTGAN_MAX_WIDTHS]; float* S[NMTGAN_MAX_WIDTHS];
   const float* scale[NMTGAN_MAX_WIDTHS]; const float* shift[NMTGAN_MAX_WIDTHS];
   int w[NMTGAN_MAX_WIDTHS], nf[NMTGAN_MAX_WIDTHS], nfp[NMTGAN_MAX_WIDTHS];
+  void* wt[NMTGAN_MAX_WIDTHS];                 // scratch of the table build: the filter bank in tap-major rows
 };
+// filter bank Wt[nf][w taps][row_bytes] -> out[w * nfp][row_bytes], row j * nfp + f = tap j of filter f (zero for f >= nf)
+int launch_table_weights(const void* wt, int w, int nf, int nfp, int row_bytes, void* out, hipStream_t st);
 // y[B][T] -> S and the window values win_vals[B*T][Fp] = relu(bn(conv)) of every window of y
 int launch_table_prefix(const ConvTable& t, const int32_t* y, int B, float* win_vals, hipStream_t st);
 // pooled[r][:] = max(pooled[r][:], max over the windows of row r that hold a sampled token)

@@ -430,7 +430,6 @@ static int disc_features_chunk(const nmtgan_discriminator* d, const nmtgan_disc_
   };
   if (table) {
     // every window that holds a sampled token, as gathered rows of the per-(token, tap) tables
-    prof::Hint ph(prof::GEMM_CONV);
     NMTGAN_TRY(launch_table_conv(*table, ids, reuse->row_b, reuse->row_g, rows, b.pooled, st));
   }
   int col = 0;
@@ -567,9 +566,9 @@ static int bucket_tables(const nmtgan_discriminator* d, const nmtgan_disc_tower&
 }
 
 // Table form of the target tower's conv for the rollouts (disc_table.hip): P_w[v][j][:] = E[v] . W_w[j] for the whole
-// vocabulary, one GEMM problem per (width, tap) over the embedding table (M = vocab, K = one token's operand row,
-// N = n_filters, output row stride w * nfp), in grouped persistent launches.  Split-precision operands give an fp32
-// table, 16-bit operands a table of their own type, fp32 operands an fp32 table.
+// vocabulary, one GEMM per width over the embedding table (M = vocab, K = one token's operand row, N = w * nfp: the
+// filter bank re-laid in tap-major rows, so an output row is a token's whole entry [w][nfp], pad columns zero).
+// Split-precision operands give an fp32 table, 16-bit operands a table of their own type, fp32 operands an fp32 table.
 static int conv_table_dtype(const nmtgan_discriminator* d) { return d->gemm_split ? NMTGAN_F32 : d->op_dtype; }
 static int conv_table_nfp(const nmtgan_discriminator* d, int nf) {        // table rows padded to whole 128-byte lines
   const int per = 128 / dtype_size(conv_table_dtype(d));
@@ -582,22 +581,19 @@ static int64_t conv_table_bytes(const nmtgan_discriminator* d) {
   return n;
 }
 static int build_conv_table(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const ConvTable& t, hipStream_t st) {
-  const int E = disc_ew(d), op = d->op_dtype, es = dtype_size(op), tes = dtype_size(t.dtype);
-  std::vector<nmtgan_gemm_args> probs;
+  const int E = disc_ew(d), op = d->op_dtype, es = dtype_size(op);
   for (int i = 0; i < d->n_widths; ++i) {
     const int w = d->widths[i];
-    for (int j = 0; j < w; ++j) {
-      nmtgan_gemm_args a{};
-      a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
-      a.A = tw.emb; a.lda = E; a.M = d->vocab; a.K = E; a.N = d->n_filters[i];
-      a.Wt = at(tw.conv_w[i], (int64_t)j * E, es); a.ldw = (int64_t)w * E;
-      a.n_seg = 1; a.seg_width = a.N; a.out[0] = at(t.tab[i], (int64_t)j * t.nfp[i], tes); a.ldo[0] = (int64_t)w * t.nfp[i];
-      a.out_f32[0] = t.dtype == NMTGAN_F32 ? 1 : 0; a.seg_scale[0] = 1.f;
-      probs.push_back(a);
-    }
+    NMTGAN_TRY(launch_table_weights(tw.conv_w[i], w, d->n_filters[i], t.nfp[i], E * es, t.wt[i], st));
+    nmtgan_gemm_args a{};
+    a.op_dtype = op; a.epilogue = NMTGAN_EPI_LINEAR;
+    a.A = tw.emb; a.lda = E; a.M = d->vocab; a.K = E; a.N = w * t.nfp[i]; a.Wt = t.wt[i];
+    a.n_seg = 1; a.seg_width = a.N; a.out[0] = t.tab[i]; a.ldo[0] = a.N;
+    a.out_f32[0] = t.dtype == NMTGAN_F32 ? 1 : 0; a.seg_scale[0] = 1.f;
+    prof::Hint ph(prof::GEMM_CONV);
+    NMTGAN_TRY(launch_gemm(&a, st));
   }
-  prof::Hint ph(prof::GEMM_CONV);
-  return launch_gemm_group(probs.data(), (int)probs.size(), st, 0);
+  return 0;
 }
 
 // C[b*T + p][Fp] = relu(bn(conv)) of every window p of rows sentences (one "sentence" of rows*T tokens with
@@ -762,7 +758,10 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   static const bool table_env = [] { const char* e = getenv("NMTGAN_CONV_TABLE"); return !e || atoi(e) != 0; }();
   const int64_t table_cap = p->conv_table_max_bytes > 0 ? p->conv_table_max_bytes : (int64_t)96 << 30;
   b.table = ConvTable{};
-  b.use_table = table_env && p->conv_table >= 0 && b.reuse && p->T <= TABLE_MAX_LEN && conv_table_bytes(d) <= table_cap;
+  // (an fp32 discriminator - the parity tier - keeps the GEMM form unless the plan asks for the tables: one fp32
+  // rounding per (token, tap) entry is a little more than the matrix cores' own accumulation loses)
+  b.use_table = table_env && (p->conv_table > 0 || (p->conv_table == 0 && d->op_dtype != NMTGAN_F32)) && b.reuse &&
+                p->T <= TABLE_MAX_LEN && conv_table_bytes(d) <= table_cap;
   if (b.use_table) {
     ConvTable& t = b.table;
     t.n_widths = d->n_widths; t.T = p->T; t.Fp = d->Fp; t.vocab = d->vocab; t.dtype = conv_table_dtype(d);
@@ -772,6 +771,7 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
       t.scale[i] = d->tgt.conv_scale[i]; t.shift[i] = d->tgt.conv_shift[i];
       t.tab[i] = ar.take((size_t)d->vocab * w * t.nfp[i] * dtype_size(t.dtype));
       t.S[i] = ar.get<float>((size_t)p->B * (p->T - w + 1) * (w > 1 ? w - 1 : 1) * t.nfp[i]);
+      t.wt[i] = ar.take((size_t)w * t.nfp[i] * disc_ew(d) * dtype_size(d->op_dtype));
     }
   }
   b.bucket = BucketReuse{};

@@ -101,7 +101,7 @@ class Model(object):
         self.group_slots = True        # 32 // rollnum prefix groups of a sentence per attention workgroup
         self.conv_bucket_taps = 0      # partial-window reuse in the discriminator: 0 = library default, < 0 off
         self.conv_table = 0            # table form of the rollouts' conv (per-(token, tap) filter responses of the whole
-        #                                vocabulary, rebuilt inside every get_reward): 0 = library default (on), < 0 off
+        #                                vocabulary, rebuilt inside every get_reward): 0 = library default (on, except fp32 tier), > 0 on, < 0 off
         self.conv_table_max_bytes = 0  # 0 = library default (96 GiB of workspace for the tables)
         self.aux_gemm_wgs = 0          # 0 = library default
         self.aux_min_rows = 0

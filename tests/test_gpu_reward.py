@@ -226,3 +226,45 @@ def test_hip_graph_replay_equals_stream_launches(cuda, setup, overlap, precision
     b = prep.replay().clone()
     torch.cuda.synchronize()
     assert torch.equal(a, ref) and torch.equal(b, ref)
+
+
+def test_get_reward_conv_table_fp32(cuda, setup):
+    """The table form of the rollouts' conv (per-(token, tap) filter responses of the whole vocabulary, windows
+    gathered from them; cnn_discriminator.py:88-109, 461-477) on fp32 operands: rewards within 1e-5 of the oracle on the
+    batch with an early </S>, an empty and a padded-source row, under tiny discriminator chunks too, and the scores of
+    the two chunkings equal bit for bit."""
+    s = setup
+    m, disc = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], "fp32", T)
+    m.conv_table = 1
+    r = m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, disc, max_len=T, bias_num=0.6, uniforms=s["u"], return_details=True)
+    p = m.last_details["p_rows"].copy()
+    assert np.abs(r - s["ref_r"]).max() < 1e-5 * max(1.0, np.abs(s["ref_r"]).max())
+    m.disc_chunk_rows, m.overlap = 3, False
+    r2 = m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, disc, max_len=T, bias_num=0.6, uniforms=s["u"], return_details=True)
+    assert np.array_equal(m.last_details["p_rows"], p) and np.array_equal(r2, r)
+    m.conv_table = -1                                      # the conv GEMMs on the same rollouts
+    m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, disc, max_len=T, bias_num=0.6, uniforms=s["u"], return_details=True)
+    assert np.abs(m.last_details["p_rows"] - p).max() < 2e-6
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16", "fp16x3"])
+def test_conv_table_and_gemm_form_agree(cuda, setup, precision):
+    """Both forms of the rollouts' conv score the same rollouts (the generator does not see the choice); each stays
+    within the tier's P(real) bound of the fp64 oracle discriminator."""
+    s = setup
+    m, disc = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], precision, T)
+    out = {}
+    for form in (0, -1):
+        m.conv_table = form
+        m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, disc, max_len=T, bias_num=0.6, uniforms=s["u"], return_details=True)
+        out[form] = m.last_details
+    plan = out[0]["plan"]
+    n = plan.n_rows
+    assert np.array_equal(out[0]["rollouts"], out[-1]["rollouts"])
+    rolls = out[0]["rollouts"][:n]
+    p_ref = O.disc_forward(s["Wd64"], s["dcfg"], rolls.T, s["xp"][plan.row_b].T).numpy()[:, 1]
+    _, p_tol = _TIER_BOUNDS[precision]
+    for form in (0, -1):
+        err = np.abs(out[form]["p_rows"][:n] - p_ref).max()
+        print("%s conv form %d: P(real) abs err %.3g" % (precision, form, err))
+        assert err < p_tol, (form, err)
