@@ -418,8 +418,9 @@ typedef struct {
                                        partial sum from a pass over y_sample) - HBM-bound reads in place of the conv GEMMs,
                                        which recompute every (token, tap) product ~ n_rows * T / vocab times.
                                        0 = default (on for a 16-bit or gemm_split discriminator when the tables fit
-                                       conv_table_max_bytes; an fp32 discriminator keeps the GEMM form), > 0 = on for
-                                       every op dtype (still subject to the size cap), < 0 = off */
+                                       conv_table_max_bytes and n_rows * T >= 4 * vocab - fewer rollout tokens than that
+                                       do not repay a pass over the vocabulary; an fp32 discriminator keeps the GEMM
+                                       form), > 0 = on for every op dtype and size (still subject to the cap), < 0 = off */
   int64_t conv_table_max_bytes;     /* 0 = default (96 GiB) */
 } nmtgan_reward_plan;
 size_t nmtgan_rollout_reward_workspace_bytes(const nmtgan_generator* g, const nmtgan_discriminator* d,

@@ -15,8 +15,6 @@
 
 namespace nmtgan {
 
-namespace {
-
 struct TableParams {
   const void* tab[NMTGAN_MAX_WIDTHS];
   float* S[NMTGAN_MAX_WIDTHS];
@@ -162,7 +160,7 @@ __global__ __launch_bounds__(256) void table_weights_kernel(const char* wt, int 
   reinterpret_cast<uint4*>(out + row * row_bytes)[c] = v;
 }
 
-int fill(const ConvTable& t, TableParams& p) {
+static int fill_table_params(const ConvTable& t, TableParams& p) {
   NMTGAN_REQUIRE(t.n_widths > 0 && t.n_widths <= NMTGAN_MAX_WIDTHS && t.T > 0 && t.T <= TABLE_MAX_LEN && t.vocab > 0 &&
                      valid_op_dtype(t.dtype), "conv table: bad geometry");
   const int vn = 16 / dtype_size(t.dtype);
@@ -181,8 +179,6 @@ int fill(const ConvTable& t, TableParams& p) {
   return 0;
 }
 
-}  // namespace
-
 int launch_table_weights(const void* wt, int w, int nf, int nfp, int row_bytes, void* out, hipStream_t st) {
   prof::Scope prof_scope(prof::DISC_SMALL, st);
   NMTGAN_REQUIRE(wt && out && w > 0 && nf > 0 && nfp >= nf && row_bytes > 0 && row_bytes % 16 == 0, "table_weights: bad arguments");
@@ -197,7 +193,7 @@ int launch_table_prefix(const ConvTable& t, const int32_t* y, int B, float* win_
   prof::Scope prof_scope(prof::CONV_TABLE, st);
   if (B == 0) return 0;
   TableParams p{};
-  NMTGAN_TRY(fill(t, p));
+  NMTGAN_TRY(fill_table_params(t, p));
   NMTGAN_REQUIRE(y && win_vals && B > 0 && B <= 65535, "table_prefix: bad arguments");
   p.ids = y; p.out = win_vals;
   const dim3 grid(t.T, B, t.n_widths);
@@ -211,7 +207,7 @@ int launch_table_conv(const ConvTable& t, const int32_t* ids, const int32_t* row
   prof::Scope prof_scope(prof::CONV_TABLE, st);
   if (rows == 0) return 0;
   TableParams p{};
-  NMTGAN_TRY(fill(t, p));
+  NMTGAN_TRY(fill_table_params(t, p));
   NMTGAN_REQUIRE(ids && row_b && row_g && pooled && rows > 0, "table_conv: bad arguments");
   p.ids = ids; p.row_b = row_b; p.row_g = row_g; p.out = pooled;
   const dim3 grid(rows, t.n_widths);

@@ -760,8 +760,11 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
   b.table = ConvTable{};
   // (an fp32 discriminator - the parity tier - keeps the GEMM form unless the plan asks for the tables: one fp32
   // rounding per (token, tap) entry is a little more than the matrix cores' own accumulation loses)
-  b.use_table = table_env && (p->conv_table > 0 || (p->conv_table == 0 && d->op_dtype != NMTGAN_F32)) && b.reuse &&
-                p->T <= TABLE_MAX_LEN && conv_table_bytes(d) <= table_cap;
+  // By default only when the rollouts hold at least four tokens per vocabulary entry: the tables cost one product per
+  // (vocabulary entry, tap), the conv GEMMs one per (rollout token, tap) less what the prefix reuse saves.
+  const bool table_pays = (int64_t)p->n_rows * p->T >= 4 * (int64_t)d->vocab;
+  b.use_table = table_env && (p->conv_table > 0 || (p->conv_table == 0 && d->op_dtype != NMTGAN_F32 && table_pays)) &&
+                b.reuse && p->T <= TABLE_MAX_LEN && conv_table_bytes(d) <= table_cap;
   if (b.use_table) {
     ConvTable& t = b.table;
     t.n_widths = d->n_widths; t.T = p->T; t.Fp = d->Fp; t.vocab = d->vocab; t.dtype = conv_table_dtype(d);

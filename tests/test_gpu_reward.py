@@ -254,17 +254,17 @@ def test_conv_table_and_gemm_form_agree(cuda, setup, precision):
     s = setup
     m, disc = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], precision, T)
     out = {}
-    for form in (0, -1):
+    for form in (1, -1):
         m.conv_table = form
         m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, disc, max_len=T, bias_num=0.6, uniforms=s["u"], return_details=True)
         out[form] = m.last_details
-    plan = out[0]["plan"]
+    plan = out[1]["plan"]
     n = plan.n_rows
-    assert np.array_equal(out[0]["rollouts"], out[-1]["rollouts"])
-    rolls = out[0]["rollouts"][:n]
+    assert np.array_equal(out[1]["rollouts"], out[-1]["rollouts"])
+    rolls = out[1]["rollouts"][:n]
     p_ref = O.disc_forward(s["Wd64"], s["dcfg"], rolls.T, s["xp"][plan.row_b].T).numpy()[:, 1]
     _, p_tol = _TIER_BOUNDS[precision]
-    for form in (0, -1):
+    for form in (1, -1):
         err = np.abs(out[form]["p_rows"][:n] - p_ref).max()
         print("%s conv form %d: P(real) abs err %.3g" % (precision, form, err))
         assert err < p_tol, (form, err)
