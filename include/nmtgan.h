@@ -109,7 +109,8 @@ int nmtgan_gemm(const nmtgan_gemm_args* a, void* stream);
 /* n independent problems in as few launches as possible: one persistent kernel walks the tiles of up to 24 problems
  * (longest k-loop first), so problems with fewer tiles than the chip has CUs - the per-width, per-row-range conv
  * products of the discriminator, cnn_discriminator.py:461-477 - fill it together.  All problems share op dtype and
- * epilogue: CONVMAX (with or without the additive term) or LINEAR with n_seg = 1, an fp32 output and seg_scale 1.
+ * epilogue: CONVMAX (with or without the additive term) or LINEAR with n_seg = 1, an fp32 or op-dtype output (out_f32
+ * 1 or 0) and seg_scale 1.
  * Results are those of n nmtgan_gemm calls (same k order per output element). */
 int nmtgan_gemm_grouped(const nmtgan_gemm_args* a, int n, void* stream);
 

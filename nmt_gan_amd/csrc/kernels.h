@@ -6,8 +6,8 @@
 namespace nmtgan {
 
 int launch_gemm(const nmtgan_gemm_args* a, hipStream_t st);
-// n independent problems of one epilogue kind (CONVMAX - with or without the additive term - or LINEAR with one fp32
-// output) in one persistent launch per 24 problems; min_tiles > 0 leaves problems of at least that many 256x128 tiles to
+// n independent problems of one epilogue kind (CONVMAX - with or without the additive term - or LINEAR with one fp32 or
+// op-dtype output) in one persistent launch per 24 problems; min_tiles > 0 leaves problems of at least that many 256x128 tiles to
 // the single-problem kernels
 int launch_gemm_group(const nmtgan_gemm_args* args, int n, hipStream_t st, int min_tiles = 0);
 int launch_gemm_stats(int op_dtype, const void* W, int V, const void* X, int rows, int K, float2* stats,

@@ -167,7 +167,8 @@ def test_gemm_convmax(cuda, op):
 def test_gemm_grouped_equals_single_launches(cuda, op):
     """nmtgan_gemm_grouped: conv problems of different widths, row counts and window ranges in ONE persistent launch
     give the bits of one nmtgan_gemm call each (same k order per output element); with the additive term (the part of
-    a window's sum that comes from a table) they match the fp64 restatement; LINEAR problems with fp32 output too."""
+    a window's sum that comes from a table) they match the fp64 restatement; LINEAR problems with an fp32 output or one
+    in the operand type too."""
     L = _lib()
     g = torch.Generator().manual_seed(21)
     dt = _TD[op]
@@ -239,6 +240,24 @@ def test_gemm_grouped_equals_single_launches(cuda, op):
     torch.cuda.synchronize()
     for A, W, single, out in keepl:
         assert torch.equal(single, out)
+    # ... and with an output in the operand type, into a wider row (ldo > N)
+    lin, keepo = [], []
+    for (A, W, single, _) in keepl:
+        M, N = single.shape
+        single_op = _gemm(L, A, W, op=op, segs=[(N, False, 1.0)])[0]
+        out = torch.zeros((M, N + 24), device=cuda, dtype=dt)
+        a = L.GemmArgs()
+        a.op_dtype, a.epilogue, a.A, a.Wt, a.M, a.N, a.K, a.lda = _code(L, op), L.EPI_LINEAR, A.data_ptr(), W.data_ptr(), M, N, A.shape[1], A.shape[1]
+        a.n_seg, a.seg_width = 1, N
+        a.out[0], a.ldo[0], a.out_f32[0], a.seg_scale[0] = out.data_ptr(), N + 24, 0, 1.0
+        lin.append(a)
+        keepo.append((single_op, out))
+    arr = (L.GemmArgs * len(lin))(*lin)
+    L.check(L.lib.nmtgan_gemm_grouped(arr, len(lin), L.stream_ptr()), "gemm_grouped linear op-dtype output")
+    torch.cuda.synchronize()
+    for single_op, out in keepo:
+        N = single_op.shape[1]
+        assert torch.equal(single_op, out[:, :N]) and float(out[:, N:].abs().max()) == 0.0
 
 
 def test_gemm_grouped_many_problems(cuda):
