@@ -208,15 +208,16 @@ def test_get_reward_16bit_token_agreement_and_rewards(cuda, d, heads, precision)
     assert np.all(r[s["mask"] == 0] == 0)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16x3"])
+@pytest.mark.parametrize("precision,conv_table", [("bf16", 0), ("fp16x3", 0), ("fp16x3", 1), ("fp16", 1)])
 @pytest.mark.parametrize("overlap", [False, True])
-def test_hip_graph_replay_equals_stream_launches(cuda, setup, overlap, precision):
+def test_hip_graph_replay_equals_stream_launches(cuda, setup, overlap, precision, conv_table):
     """The library only enqueues (no allocation, synchronisation or host callback inside nmtgan_rollout_reward),
-    so a whole get_reward - both streams of the two-stream schedule included - can be captured into one HIP graph;
-    replaying it gives the bits the plain launches give."""
+    so a whole get_reward - both streams of the two-stream schedule included, and the table form of the rollouts' conv
+    with the table GEMMs it starts with - can be captured into one HIP graph; replaying it gives the bits the plain
+    launches give."""
     s = setup
     m, disc = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], precision, T)
-    m.overlap = overlap
+    m.overlap, m.conv_table = overlap, conv_table
     prep = m.prepare_reward(s["x"], s["xp"], s["y"], s["mask"], R, disc, T, 0.6, torch.from_numpy(s["u"]))
     ref = prep.launch().clone()
     torch.cuda.synchronize()
