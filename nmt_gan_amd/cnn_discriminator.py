@@ -79,7 +79,7 @@ class DisCNN(object):
         self.optimizer_name = optimizer          # cnn_discriminator.py:153-166; RMSPropOptimizer(0.0001) for 'rmsprop'
         self.learning_rate = 1e-4
         from .model import _Saver
-        self.saver = _Saver(self.save, self.restore)      # gan_train.py:161: discriminator.saver.save(sess, saveto)
+        self.saver = _Saver(self, "save", "restore")      # gan_train.py:161: discriminator.saver.save(sess, saveto)
         self.reload = bool(reload)
         if self.reload:                # cnn_discriminator.py:209-217: saver.restore(sess, saveto) in the constructor
             self.restore(saveto)

@@ -24,6 +24,7 @@ import codecs
 import ctypes as C
 import logging
 import math
+import weakref
 from typing import Dict, Optional
 
 import numpy as np
@@ -51,18 +52,28 @@ class _Saver(object):
     """Stand-in for the `saver` attribute (a tf.train.Saver) the reference's drivers use:
     `generator.saver.save(generator.sess, path)` (gan_train.py:118, 134), `discriminator.saver.save(
     discriminator.sess, discriminator.saveto)` (gan_train.py:161), `saver.restore(sess, path)` (model.py:432).
-    `sess` is accepted and ignored; the files are TF V2 checkpoint bundles."""
+    `sess` is accepted and ignored; the files are TF V2 checkpoint bundles.
+    The owner is held weakly: a model and its saver form no reference cycle, so dropping the last reference to a model
+    returns its device memory (tens of GiB of workspace at benchmark size) at once instead of at the next cyclic
+    garbage collection."""
 
-    def __init__(self, save_fn, restore_fn):
-        self._save_fn, self._restore_fn = save_fn, restore_fn
+    def __init__(self, owner, save_name, restore_name):
+        self._owner = weakref.ref(owner)
+        self._save_name, self._restore_name = save_name, restore_name
+
+    def _call(self, name, path):
+        owner = self._owner()
+        if owner is None:
+            raise RuntimeError("saver: the model it belongs to no longer exists")
+        getattr(owner, name)(path)
 
     def save(self, sess, save_path, global_step=None, **_ignored):
         path = str(save_path) if global_step is None else "%s-%d" % (save_path, int(global_step))
-        self._save_fn(path)
+        self._call(self._save_name, path)
         return path
 
     def restore(self, sess, save_path):
-        self._restore_fn(str(save_path))
+        self._call(self._restore_name, str(save_path))
 
 
 class Model(object):
@@ -112,7 +123,7 @@ class Model(object):
         self.reward_seed_base = 0      # seed of the n-th get_reward call without uniforms=/seed= is base + n
         self._reward_calls = 0
         self._gather_bufs = {}
-        self.saver = _Saver(self.save, lambda path: self.init_and_restore(modelFile=path))
+        self.saver = _Saver(self, "save", "_restore_from")
 
     # ------------------------------------------------------------------ graph-building surface
     def build_train_model(self):
@@ -420,6 +431,9 @@ class Model(object):
             out[name] = np.ascontiguousarray(a.reshape(shp))
         return out
 
+    def _restore_from(self, path):
+        self.init_and_restore(modelFile=path)
+
     def save(self, prefix):
         """saver.save(sess, prefix) (gan_train.py:118): a TF V2 bundle of the trainable variables."""
         from . import tf_checkpoint
@@ -554,14 +568,15 @@ class Model(object):
         world, rank = 1, 0
         if shard and torch.distributed.is_available() and torch.distributed.is_initialized():
             world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+        ct = self.conv_form(mask, rollnum, T, disc)
         if world > 1 and B < world:
-            out = self._reward_roll_sharded(x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, world, rank)
+            out = self._reward_roll_sharded(x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, world, rank, ct)
             torch.cuda.synchronize(self.device)
             return out.cpu().numpy()
         bounds = split_bounds(B, world)
         b0, b1 = bounds[rank], bounds[rank + 1]
         local = self._reward_local(x[b0:b1], x_pad_T[b0:b1], y[b0:b1], mask[b0:b1], rollnum, disc, T, bias_num, u,
-                                   b_offset=b0, B_global=B, return_details=return_details)
+                                   b_offset=b0, B_global=B, return_details=return_details, conv_table=ct)
         if world == 1:
             out = local
         else:
@@ -569,7 +584,19 @@ class Model(object):
         torch.cuda.synchronize(self.device)
         return out.cpu().numpy()
 
-    def _reward_roll_sharded(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, world, rank):
+    def conv_form(self, mask, rollnum, T, disc):
+        """Which form of the rollouts' discriminator conv a call takes, as nmtgan_reward_plan.conv_table (> 0 table form,
+        < 0 conv GEMMs), decided ONCE from the whole batch: the two forms round differently, so every shard of a job must
+        take the form the unsharded call takes for its scores to be the same bits.  The rule is the library's default -
+        the table form when the rollouts hold at least four tokens per vocabulary entry, never for the fp32 tier -
+        applied to the global row count; Model.conv_table != 0 overrides it."""
+        if int(self.conv_table) != 0:
+            return int(self.conv_table)
+        lens = (np.asarray(mask) != 0).sum(axis=1)
+        n_rows = int(rollnum) * int(np.clip(lens - 1, 0, None).sum())
+        return 1 if (getattr(disc, "precision", None) != "fp32" and n_rows * int(T) >= 4 * int(disc.vocab_size)) else -1
+
+    def _reward_roll_sharded(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, world, rank, conv_table=None):
         """Fewer sentences than ranks: the (sentence, roll) units are cut across the ranks (all prefixes of a
         unit stay on one rank).  A rank scores its pieces - one sentence with a range of rolls each, uniforms
         addressed by global sentence and roll - and leaves P(real) of every rollout in a [units, T] block
@@ -581,7 +608,7 @@ class Model(object):
         part = torch.zeros((max(u1 - u0, 0), T), dtype=torch.float32, device=dev)
         for b, r0, r1 in pieces:
             prep = self.prepare_reward(x[b:b + 1], x_pad_T[b:b + 1], y[b:b + 1], mask[b:b + 1], r1 - r0, disc, T, None, u,
-                                       b_offset=b, B_global=B, r_offset=r0, return_details="scores")
+                                       b_offset=b, B_global=B, r_offset=r0, return_details="scores", conv_table=conv_table)
             prep.launch()
             plan, d = prep.plan, prep.details
             rows = torch.arange(r0, r1, device=dev) + (b * R - u0)
@@ -605,11 +632,12 @@ class Model(object):
               "nmtgan_reward_reduce")
         return rewards
 
-    def _reward_local(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, b_offset, B_global, return_details):
+    def _reward_local(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, b_offset, B_global, return_details,
+                      conv_table=None):
         if x.shape[0] == 0:
             return torch.zeros((0, T), dtype=torch.float32, device=self.device)
         prep = self.prepare_reward(x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, b_offset=b_offset,
-                                   B_global=B_global, return_details=return_details)
+                                   B_global=B_global, return_details=return_details, conv_table=conv_table)
         rewards = prep.launch()
         if return_details:
             torch.cuda.synchronize(self.device)
@@ -617,9 +645,11 @@ class Model(object):
         return rewards
 
     def prepare_reward(self, x, x_pad_T, y, mask, rollnum, disc, T, bias_num, u, b_offset=0, B_global=None,
-                       return_details=False, own_workspace=False, stream=None, r_offset=0):
+                       return_details=False, own_workspace=False, stream=None, r_offset=0, conv_table=None):
         """Host half of get_reward: build the rollout plan, upload ids/tables, size the workspace.
-        Returns a PreparedReward whose launch() only enqueues device work (inputs resident in HBM)."""
+        Returns a PreparedReward whose launch() only enqueues device work (inputs resident in HBM).
+        conv_table: the plan field of that name (None: Model.conv_table, 0 = the library's rule on THIS shard's rows;
+        get_reward passes the choice it made for the whole batch, see conv_form)."""
         dev = self.device
         check_pairing(self.precision, getattr(disc, "precision", None))
         x = np.ascontiguousarray(np.asarray(x), dtype=np.int32)
@@ -662,7 +692,8 @@ class Model(object):
         p.disc_chunk_rows = self.disc_chunk_rows
         p.rewards = ptr(t["rewards"])
         p.conv_bucket_taps = int(self.conv_bucket_taps)
-        p.conv_table, p.conv_table_max_bytes = int(self.conv_table), int(self.conv_table_max_bytes)
+        p.conv_table = int(self.conv_table if conv_table is None else conv_table)
+        p.conv_table_max_bytes = int(self.conv_table_max_bytes)
         if "grp_table" in t:
             p.grp_table, p.grp_slots, p.grp_live = ptr(t["grp_table"]), int(plan.grp_slots), grp_live.ctypes.data
         if self.overlap:

@@ -73,8 +73,12 @@ def world(cuda):
 
     def pair(precision, vehicle):
         if (precision, vehicle) not in cache:
-            if precision != "fp32":
-                cache.clear()                              # one 16-bit pair alive at a time
+            if precision != "fp32":                        # one 16-bit pair alive at a time, its workspace (25-49 GiB
+                for k in [k for k in cache if k[0] != "fp32"]:     # with the conv tables) returned before the next
+                    del cache[k]
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
             m = N.Model(mcfg, precision=precision)
             m.build_rollout_generate(T)
             m.init_and_restore(weights=Wg[vehicle])

@@ -150,6 +150,84 @@ def test_tier_pairing_is_checked_on_both_sides():
         check_pairing(gen, disc)
 
 
+def test_conv_form_is_chosen_once_per_batch_and_sized_by_the_library():
+    """The table form of the rollouts' conv: the facade picks the form from the WHOLE batch (so the shards of a job and
+    the unsharded call agree), the library's workspace query grows by the tables exactly when the form is on, and a cap
+    below the tables' size switches it off."""
+    import types
+    from nmt_gan_amd import _lib
+    from nmt_gan_amd.model import Model
+    T, R, V = 50, 16, 32000
+    disc = types.SimpleNamespace(precision="fp16", vocab_size=V)
+    me = types.SimpleNamespace(conv_table=0)
+    full = np.ones((64, T), np.float32)
+    assert Model.conv_form(me, full, R, T, disc) == 1                      # 50,176 rollouts x 50 tokens over 32,000 entries
+    assert Model.conv_form(me, full[:2], R, T, disc) == -1                 # 1,568 rollouts: below 4 tokens per entry
+    assert Model.conv_form(me, np.zeros((64, T), np.float32), R, T, disc) == -1
+    assert Model.conv_form(me, full, R, T, types.SimpleNamespace(precision="fp32", vocab_size=V)) == -1
+    me.conv_table = -1
+    assert Model.conv_form(me, full, R, T, disc) == -1
+    me.conv_table = 1
+    assert Model.conv_form(me, full[:1], R, T, disc) == 1
+    # library side: workspace with the tables on / off / capped
+    g = _lib.Generator()
+    g.op_dtype, g.d, g.heads, g.n_blocks, g.vocab_src, g.vocab_dst, g.max_pos = _lib.NMTGAN_F16, 64, 4, 2, 512, 512, 256
+    g.emb_src = g.emb_dst = g.softmax_w = g.timing = 4096
+    d = _lib.Discriminator()
+    d.op_dtype, d.max_len, d.dim_word, d.vocab, d.vocab_s, d.n_widths, d.F, d.Fp = _lib.NMTGAN_F16, 12, 64, 512, 512, 2, 260, 320
+    d.widths[0], d.widths[1], d.n_filters[0], d.n_filters[1] = 1, 5, 110, 150
+    n_rows = 8
+    live = (C.c_int32 * 1)(n_rows)
+    off = (C.c_int64 * 1)(0)
+    row_g = (C.c_int32 * n_rows)(*([3] * n_rows))
+    p = _lib.RewardPlan()
+    p.B, p.Ls, p.T, p.rollnum, p.n_rows, p.n_steps = 2, 12, 12, 2, n_rows, 0
+    p.live, p.step_off_host, p.row_g_host = C.addressof(live), C.addressof(off), C.addressof(row_g)
+    size = lambda: _lib.lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(d), C.byref(p))
+    p.conv_bucket_taps = -1                                                # (the GEMM form's own tables off: sizes comparable)
+    p.conv_table = -1
+    off_bytes = size()
+    p.conv_table = 0
+    assert size() == off_bytes                                             # 8 rollouts do not repay a pass over 512 entries
+    p.conv_table = 1
+    tables = 512 * (1 * 128 + 5 * 192) * 2                                 # vocab x sum(w x filters padded to 64) x fp16
+    assert size() >= off_bytes + tables - 4096 and size() < off_bytes + 2 * tables
+    d.gemm_split = 1                                                       # split form: fp32 entries, rows padded to 32
+    on3 = size()
+    p.conv_table = -1
+    assert on3 >= size() + 512 * (1 * 128 + 5 * 160) * 4 - 4096
+    p.conv_table, p.conv_table_max_bytes = 1, 1000
+    assert size() == _lib.lib.nmtgan_rollout_reward_workspace_bytes(C.byref(g), C.byref(d), C.byref(p))
+    p.conv_table = -1
+    capped_off = size()
+    p.conv_table = 1
+    assert size() == capped_off                                            # the cap wins over conv_table = 1
+
+
+def test_models_are_freed_by_reference_counting():
+    """A Model / DisCNN and its reference-named `saver` form no cycle: the last reference gone, the object (and with it
+    tens of GiB of device workspace at benchmark size) is released at once, not at the next cyclic collection."""
+    import gc
+    import weakref
+    import nmt_gan_amd as N
+    from nmt_gan_amd.utils import AttrDict as Cfg
+    mcfg = Cfg(hidden_units=64, num_blocks=2, num_heads=4, src_vocab_size=512, dst_vocab_size=512, scale_embedding=True,
+               residual_dropout_rate=0.0, train=Cfg(shared_embedding=False))
+    gc.collect()
+    gc.disable()
+    try:
+        m = N.Model(mcfg, precision="fp16")
+        d = N.DisCNN(None, 12, 2, 512, 4, 64, [1, 5], [110, 150], vocab_size_s=512, precision="fp16")
+        saver = m.saver
+        rm, rd = weakref.ref(m), weakref.ref(d)
+        del m, d
+        assert rm() is None and rd() is None
+        with pytest.raises(RuntimeError):
+            saver.save(None, "/tmp/never_written")
+    finally:
+        gc.enable()
+
+
 def test_split_packers_reassemble_the_fp32_values():
     """The three split layouts (activation rows [hi | lo | hi], weight rows [hi | hi | lo], filters per tap) hold
     hi + lo = the fp32 value to 2^-22 relative, and the per-tap interleave keeps every tap next to its own lo part."""
