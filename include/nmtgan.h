@@ -345,6 +345,36 @@ int nmtgan_disc_head(const nmtgan_discriminator* d, const float* feat_t, const f
                      const int32_t* src_row, int M, float* p_real, float* probs2, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Table form of the target tower's conv + BatchNorm + ReLU + max-over-time (cnn_discriminator.py:88-109, 461-477) for
+ * the rollouts of one get_reward (model.py:303-313) - the building blocks nmtgan_rollout_reward runs when
+ * nmtgan_reward_plan.conv_table selects the form, exposed for callers that schedule the discriminator themselves.
+ * A filter of width w at window p is sum_{j<w} E[tok[p+j]] . W_w[j]: every term depends on one token and one tap, so
+ *   tab[i][v][j][0..nfp) = E[v] . W_w[j]   for the whole vocabulary (nmtgan_conv_table_build: one GEMM per width),
+ * and a window of a rollout is w gathered rows of tab added in tap order.  A rollout (b, g) keeps y[b][0..g):
+ *   S[i][b][p][j-1][0..nfp) = sum of the first j taps (1 <= j < w) of window p of y[b]   (nmtgan_conv_table_prefix,
+ *   which also writes relu(bn(conv)) of every window of y to win_vals[b*T + p][Fp] - the values behind a prefix max),
+ * and nmtgan_conv_table_rows visits the windows p >= g - w + 1 of each row, starts a window that begins inside the
+ * prefix from S[i][b][p][g-p-1], gathers the remaining taps with the row's own tokens and folds
+ * max_p relu(sum * scale + shift) into pooled[r][col_i ..] (pooled must hold the max over the windows that end inside
+ * the prefix, or zeros; col_i = filters of the widths before i).  Entries are `dtype` (NMTGAN_F16 / BF16 / F32; fp32
+ * entries are added in fp64), S is fp32, nfp[i] >= nf[i] pads a table row to whole 16-byte vectors (the library uses
+ * 128-byte lines); every table 16-byte aligned.  wt[i] is scratch of the build: w*nfp operand rows of the discriminator.
+ */
+typedef struct {
+  int n_widths, T, Fp, vocab, dtype;
+  void* tab[NMTGAN_MAX_WIDTHS];          /* [vocab][w][nfp] */
+  float* S[NMTGAN_MAX_WIDTHS];           /* [B][T-w+1][w-1][nfp] (w = 1: unused, any non-null pointer) */
+  const float* scale[NMTGAN_MAX_WIDTHS]; /* [nf] folded BatchNorm, as nmtgan_disc_tower.conv_scale / conv_shift */
+  const float* shift[NMTGAN_MAX_WIDTHS];
+  int w[NMTGAN_MAX_WIDTHS], nf[NMTGAN_MAX_WIDTHS], nfp[NMTGAN_MAX_WIDTHS];
+  void* wt[NMTGAN_MAX_WIDTHS];           /* build scratch [w*nfp][dim_word (x3 for gemm_split)] op dtype */
+} nmtgan_conv_table;
+int nmtgan_conv_table_build(const nmtgan_discriminator* d, const nmtgan_conv_table* t, void* stream);
+int nmtgan_conv_table_prefix(const nmtgan_conv_table* t, const int32_t* y, int B, float* win_vals, void* stream);
+int nmtgan_conv_table_rows(const nmtgan_conv_table* t, const int32_t* ids, const int32_t* row_b,
+                           const int32_t* row_g, int rows, float* pooled, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-prefix reward averaging.  Replaces the numpy tail of Model.get_reward (model.py:315-345):
  * Q[b,g-1] = sum_r p[grp_first[b,g-1] + r] (rolls added in r order) or rollnum adds of p_base[b]
  * when grp_first < 0 (prefix >= sentence length); Q[b,T-1] = rollnum adds of p_base[b];

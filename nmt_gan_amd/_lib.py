@@ -109,6 +109,12 @@ class DiscParams(C.Structure):
     _fields_ = [("tgt", DiscTowerParams), ("src", DiscTowerParams), ("head_w", vp), ("head_b", vp)]
 
 
+class ConvTable(C.Structure):
+    _fields_ = [("n_widths", i32), ("T", i32), ("Fp", i32), ("vocab", i32), ("dtype", i32),
+                ("tab", vp * MAX_WIDTHS), ("S", vp * MAX_WIDTHS), ("scale", vp * MAX_WIDTHS), ("shift", vp * MAX_WIDTHS),
+                ("w", i32 * MAX_WIDTHS), ("nf", i32 * MAX_WIDTHS), ("nfp", i32 * MAX_WIDTHS), ("wt", vp * MAX_WIDTHS)]
+
+
 class RewardPlan(C.Structure):
     _fields_ = [("B", i32), ("Ls", i32), ("T", i32), ("rollnum", i32), ("n_rows", i32), ("n_steps", i32),
                 ("live", vp), ("step_off_host", vp), ("step_off", vp),
@@ -127,6 +133,9 @@ EXPORTS = {
     "nmtgan_last_error": (C.c_char_p, []),
     "nmtgan_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "nmtgan_gemm_grouped": (i32, [C.POINTER(GemmArgs), i32, vp]),
+    "nmtgan_conv_table_build": (i32, [C.POINTER(Discriminator), C.POINTER(ConvTable), vp]),
+    "nmtgan_conv_table_prefix": (i32, [C.POINTER(ConvTable), vp, i32, vp, vp]),
+    "nmtgan_conv_table_rows": (i32, [C.POINTER(ConvTable), vp, vp, vp, i32, vp, vp]),
     "nmtgan_embed": (i32, [C.POINTER(EmbedArgs), vp]),
     "nmtgan_add_layernorm": (i32, [C.POINTER(AddLnArgs), vp]),
     "nmtgan_split3": (i32, [vp, i64, i32, i32, vp, vp]),

@@ -96,6 +96,18 @@ int nmtgan_gemm(const nmtgan_gemm_args* a, void* stream) { return launch_gemm(a,
 int nmtgan_gemm_grouped(const nmtgan_gemm_args* a, int n, void* stream) {
   return launch_gemm_group(a, n, (hipStream_t)stream);
 }
+int nmtgan_conv_table_build(const nmtgan_discriminator* d, const nmtgan_conv_table* t, void* stream) {
+  return conv_table_build(d, t, (hipStream_t)stream);
+}
+int nmtgan_conv_table_prefix(const nmtgan_conv_table* t, const int32_t* y, int B, float* win_vals, void* stream) {
+  if (!t) { set_error("conv_table_prefix: null table"); return -2; }
+  return launch_table_prefix(*t, y, B, win_vals, (hipStream_t)stream);
+}
+int nmtgan_conv_table_rows(const nmtgan_conv_table* t, const int32_t* ids, const int32_t* row_b, const int32_t* row_g,
+                           int rows, float* pooled, void* stream) {
+  if (!t) { set_error("conv_table_rows: null table"); return -2; }
+  return launch_table_conv(*t, ids, row_b, row_g, rows, pooled, (hipStream_t)stream);
+}
 int nmtgan_embed(const nmtgan_embed_args* a, void* stream) { return launch_embed(a, (hipStream_t)stream); }
 int nmtgan_add_layernorm(const nmtgan_addln_args* a, void* stream) {
   return launch_add_layernorm(a, (hipStream_t)stream);

@@ -62,13 +62,7 @@ int launch_bucket_finish(const float* raw, const float* S, const int32_t* row_b,
 // table form of the conv + max of the rollouts (disc_table.hip): per width i a table tab[i][vocab][w][nfp] of
 // per-(token, tap) filter responses in `dtype` and the partial sums S[i][B][T-w+1][w-1][nfp] (fp32) over y_sample
 constexpr int TABLE_MAX_LEN = 512;
-struct ConvTable {
-  int n_widths, T, Fp, vocab, dtype;
-  void* tab[NMTGAN_MAX_WIDTHS]; float* S[NMTGAN_MAX_WIDTHS];
-  const float* scale[NMTGAN_MAX_WIDTHS]; const float* shift[NMTGAN_MAX_WIDTHS];
-  int w[NMTGAN_MAX_WIDTHS], nf[NMTGAN_MAX_WIDTHS], nfp[NMTGAN_MAX_WIDTHS];
-  void* wt[NMTGAN_MAX_WIDTHS];                 // scratch of the table build: the filter bank in tap-major rows
-};
+using ConvTable = nmtgan_conv_table;
 // filter bank Wt[nf][w taps][row_bytes] -> out[w * nfp][row_bytes], row j * nfp + f = tap j of filter f (zero for f >= nf)
 int launch_table_weights(const void* wt, int w, int nf, int nfp, int row_bytes, void* out, hipStream_t st);
 // y[B][T] -> S and the window values win_vals[B*T][Fp] = relu(bn(conv)) of every window of y
@@ -76,6 +70,8 @@ int launch_table_prefix(const ConvTable& t, const int32_t* y, int B, float* win_
 // pooled[r][:] = max(pooled[r][:], max over the windows of row r that hold a sampled token)
 int launch_table_conv(const ConvTable& t, const int32_t* ids, const int32_t* row_b, const int32_t* row_g, int rows,
                       float* pooled, hipStream_t st);
+// the tables of the target tower of d (pipeline.hip; t describes them: geometry, entry type, buffers)
+int conv_table_build(const nmtgan_discriminator* d, const ConvTable* t, hipStream_t st);
 int launch_highway_gate(const float* H, const float* o, const float* t, float* out, int64_t n, hipStream_t st);
 int launch_disc_head(const float* feat_t, const float* feat_s, const int32_t* src_row, int M, int Fp,
                      const float* head_w, const float* head_b, float* p_real, float* probs2, hipStream_t st);

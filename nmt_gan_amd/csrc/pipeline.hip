@@ -596,6 +596,19 @@ static int build_conv_table(const nmtgan_discriminator* d, const nmtgan_disc_tow
   return 0;
 }
 
+int conv_table_build(const nmtgan_discriminator* d, const ConvTable* t, hipStream_t st) {
+  NMTGAN_TRY(check_disc(d));
+  NMTGAN_REQUIRE(t != nullptr && t->n_widths == d->n_widths && t->vocab == d->vocab && t->dtype == conv_table_dtype(d),
+                 "conv_table_build: the table's widths, vocabulary or entry type do not match the discriminator");
+  for (int i = 0; i < d->n_widths; ++i) {
+    NMTGAN_REQUIRE(t->w[i] == d->widths[i] && t->nf[i] == d->n_filters[i] && t->nfp[i] >= t->nf[i] &&
+                       (t->nfp[i] * dtype_size(t->dtype)) % 16 == 0 && t->tab[i] && t->wt[i] &&
+                       (uintptr_t)t->tab[i] % 16 == 0 && (uintptr_t)t->wt[i] % 16 == 0,
+                   "conv_table_build: bad entry for width %d", d->widths[i]);
+  }
+  return build_conv_table(d, d->tgt, *t, st);
+}
+
 // C[b*T + p][Fp] = relu(bn(conv)) of every window p of rows sentences (one "sentence" of rows*T tokens with
 // a pooling group of one window; windows that run over a sentence end are computed and never read)
 static int disc_window_values(const nmtgan_discriminator* d, const nmtgan_disc_tower& tw, const int32_t* ids, int rows,

@@ -45,6 +45,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
              "nmtgan_attn_group_args": (_lib.AttnGroupArgs, "out_split"), "nmtgan_sample_args": (_lib.SampleArgs, "out"),
              "nmtgan_generator": (_lib.Generator, "gemm_split"), "nmtgan_discriminator": (_lib.Discriminator, "gemm_split"),
              "nmtgan_reward_plan": (_lib.RewardPlan, "conv_table_max_bytes"),
+             "nmtgan_conv_table": (_lib.ConvTable, "wt"),
              "nmtgan_disc_tower_params": (_lib.DiscTowerParams, "hw_tr"), "nmtgan_disc_params": (_lib.DiscParams, "head_b")}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "nmtgan.h"', 'int main(void) {']
     for cname, (_, last) in pairs.items():
