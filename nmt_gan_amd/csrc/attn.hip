@@ -283,12 +283,157 @@ __global__ __launch_bounds__(256) void attn_rows_16_kernel(AttnParams p) {
   VecIO<KT, EPL>::store(reinterpret_cast<KT*>(p.out) + (int64_t)row * d + lane * EPL, o);
 }
 
+// The same kernel for calls without a padding mask (the rollout steps' self-attention, 94 % of the launches), written so
+// that the instruction stream of a wave is arithmetic and loads: the compiled loop of the kernel above spends 83 scalar
+// instructions per key (each `if (valid)` on a wave-uniform flag becomes an EXEC-mask sequence and a branch, every key
+// offset a 64-bit scalar multiply, the head reduction six run-time tests) beside 53 vector instructions; this one 22 and
+// 34.  The keys of both segments form ONE sequence of batches; a batch always loads KB keys (indices clamped to the
+// segment's last key, so the tail re-reads a valid key) and an invalid slot only gets its score replaced by -inf, which
+// makes its weight exactly 0: the sums, the running maximum and the output are the bits of the kernel above.
+// (Worth 2 % of the kernel's time, no more: it waits on memory either way - two-key batches at seven waves per SIMD
+// instead of four-key batches at four run the same.)
+// d = 64 EPL and the lanes per head (LPH = 64 / heads) are compile-time values: key offsets are shifts instead of
+// 64-bit scalar multiplies, and the head reduction has no run-time tests.
+template <typename KT, int EPL, int KB, typename QT, int LPH>
+__global__ __launch_bounds__(256) void attn_rows_16s_kernel(AttnParams p) {
+  constexpr int NV = EPL / 8;
+  constexpr float LOG2E = 1.44269504088896341f;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  constexpr int lph = LPH;
+  constexpr int d = 64 * EPL;
+  const int blk = __builtin_amdgcn_readfirstlane(p.seg1_blk ? p.seg1_blk[row] : (p.rows_per_blk > 0 ? row / p.rows_per_blk : 0));
+  int cnt1 = 0;
+  if (p.k1) cnt1 = p.seg1_cnt ? p.seg1_cnt[row] : (p.causal ? row % p.rows_per_blk + 1 : p.len1);
+  cnt1 = __builtin_amdgcn_readfirstlane(cnt1);
+  const int n2 = p.n_steps2;
+  const int nb1 = (cnt1 + KB - 1) / KB, nb = nb1 + (n2 + KB - 1) / KB;       // batches of segment 1, of both
+  const KT* k1 = reinterpret_cast<const KT*>(p.k1) + ((int64_t)blk * p.len1) * d + lane * EPL;
+  const KT* v1 = reinterpret_cast<const KT*>(p.v1) + ((int64_t)blk * p.len1) * d + lane * EPL;
+  const KT* k2 = reinterpret_cast<const KT*>(p.k2) + (int64_t)row * d + lane * EPL;
+  const KT* v2 = reinterpret_cast<const KT*>(p.v2) + (int64_t)row * d + lane * EPL;
+
+  constexpr bool DOT2 = __is_same(KT, f16_t) && __is_same(QT, f16_t);
+  float q[EPL];
+  uint4 qp[NV];
+  if constexpr (DOT2) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) qp[i] = reinterpret_cast<const uint4*>(reinterpret_cast<const KT*>(p.q) + (int64_t)row * d + lane * EPL)[i];
+  } else {
+    VecIO<QT, EPL>::load(reinterpret_cast<const QT*>(p.q) + (int64_t)row * d + lane * EPL, q);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) q[e] *= LOG2E;
+  }
+
+  float m = -INFINITY, l = 0.f;                    // m in log2 units
+  float o[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+  if (p.o_init) {
+    const int head = (lane * EPL) / (d / p.heads);
+    m = p.m_init[(int64_t)row * p.heads + head] * LOG2E;
+    l = p.l_init[(int64_t)row * p.heads + head];
+    VecIO<float, EPL>::load(p.o_init + (int64_t)row * d + lane * EPL, o);
+  }
+
+  uint4 kc[KB][NV], vc[KB][NV], kn[KB][NV], vn[KB][NV];
+  auto fetch = [&](int b, uint4 (&kr)[KB][NV], uint4 (&vr)[KB][NV]) {
+    if (b < nb1) {
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int64_t off = (int64_t)min(b * KB + u, cnt1 - 1) * d;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          kr[u][i] = reinterpret_cast<const uint4*>(k1 + off)[i];
+          vr[u][i] = reinterpret_cast<const uint4*>(v1 + off)[i];
+        }
+      }
+    } else {
+      int64_t so[KB];                              // the batch's step offsets first: KB scalar loads in flight together
+#pragma unroll
+      for (int u = 0; u < KB; ++u) so[u] = p.step_off[min((b - nb1) * KB + u, n2 - 1)];
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int64_t off = so[u] * (int64_t)d;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          kr[u][i] = reinterpret_cast<const uint4*>(k2 + off)[i];
+          vr[u][i] = reinterpret_cast<const uint4*>(v2 + off)[i];
+        }
+      }
+    }
+  };
+  auto consume = [&](int b, const uint4 (&kr)[KB][NV], const uint4 (&vr)[KB][NV]) {
+    const int nvalid = b < nb1 ? cnt1 - b * KB : n2 - (b - nb1) * KB;     // >= 1; slots u >= nvalid repeat the last key
+    float s[KB];
+    float mx = m;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      float part = 0.f;
+      if constexpr (DOT2) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          part = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, qp[i].x), __builtin_bit_cast(f16x2_t, kr[u][i].x), part, false);
+          part = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, qp[i].y), __builtin_bit_cast(f16x2_t, kr[u][i].y), part, false);
+          part = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, qp[i].z), __builtin_bit_cast(f16x2_t, kr[u][i].z), part, false);
+          part = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, qp[i].w), __builtin_bit_cast(f16x2_t, kr[u][i].w), part, false);
+        }
+      } else {
+        float kf[EPL];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) unpack8<KT>(kr[u][i], kf + 8 * i);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) part = fmaf(q[e], kf[e], part);
+      }
+      part = head_sum(part, lph);
+      if constexpr (DOT2) part *= LOG2E;
+      s[u] = u < nvalid ? part : -INFINITY;
+      mx = fmaxf(mx, s[u]);
+    }
+    const float alpha = __builtin_amdgcn_exp2f(m - mx);
+    l *= alpha;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const float w = __builtin_amdgcn_exp2f(s[u] - mx);           // exactly 0 for an invalid slot
+      l += w;
+      float vf[EPL];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) unpack8<KT>(vr[u][i], vf + 8 * i);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = fmaf(w, vf[e], o[e]);
+    }
+    m = mx;
+  };
+
+  if (nb > 0) fetch(0, kc, vc);
+  for (int b = 0; b < nb; b += 2) {
+    const bool second = b + 1 < nb;
+    if (second) fetch(b + 1, kn, vn);
+    consume(b, kc, vc);
+    if (second) {
+      if (b + 2 < nb) fetch(b + 2, kc, vc);
+      consume(b + 1, kn, vn);
+    }
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] *= inv;
+  VecIO<KT, EPL>::store(reinterpret_cast<KT*>(p.out) + (int64_t)row * d + lane * EPL, o);
+}
+
 template <typename KT, typename QT>
 static int launch_attn_t(const AttnParams& p, hipStream_t st) {
   const int epl = p.d / 64;
   dim3 grid((p.M + 3) / 4), block(256);
   if constexpr (sizeof(KT) == 2) {
     static const bool fast = [] { const char* e = getenv("NMTGAN_ATTN_FAST"); return !e || atoi(e) != 0; }();
+    static const bool lean = [] { const char* e = getenv("NMTGAN_ATTN_LEAN"); return !e || atoi(e) != 0; }();
+    const int lph = 64 / p.heads;
+    if (fast && lean && !p.mask1 && epl == 8 && lph == 8) { hipLaunchKernelGGL((attn_rows_16s_kernel<KT, 8, 4, QT, 8>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
+    if (fast && lean && !p.mask1 && epl == 16 && lph == 4) { hipLaunchKernelGGL((attn_rows_16s_kernel<KT, 16, 2, QT, 4>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
     if (fast && epl == 8) { hipLaunchKernelGGL((attn_rows_16_kernel<KT, 8, 4, QT>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
     if (fast && epl == 16) { hipLaunchKernelGGL((attn_rows_16_kernel<KT, 16, 2, QT>), grid, block, 0, st, p); NMTGAN_CHECK_LAUNCH("attn_rows"); return 0; }
   }
