@@ -120,7 +120,7 @@ TRAFFIC_KERNELS = {
     "gemm_logits": r"gemm_\w+_kernel<(unsigned short|_Float16), (2|100)[,>]",     # 2 in the bf16 summary, made by an earlier build
     # (the split-precision tier's fp32 row kernel also serves its 24 encoder / prefill launches, 8 % of the launches)
     # the rollout steps' self-attention: one per-row launch over shared prefix + private suffix
-    "attn_self_step": r"attn_rows_(bf16|16)_kernel|attn_rows_kernel<float",
+    "attn_self_step": r"attn_rows_(bf16|16s?)_kernel|attn_rows_kernel<float",
     "add_layernorm": r"addln_kernel",
     "sampler_rows": r"sample_kernel",
     "conv_table": r"table_conv_kernel",
