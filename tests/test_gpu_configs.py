@@ -64,6 +64,16 @@ def test_c1_fp32_tier_reproduces_oracle_golden(cuda):
     assert err < 1e-5
     assert np.abs(r - g["rewards_bias06"]).max() < 0.26            # a flipped rollout moves its cell by < 1/rollnum
     assert np.array_equal(m.generate_step(g["x"]), g["greedy"])
+    # the table form of the rollouts' conv on the same call, at the real vocabulary (forced on: by the default rule C1's
+    # 856 rollouts stay on the conv GEMMs): the same rollouts, rewards within 1e-5 of the golden as well
+    m.conv_table = 1
+    rt = m.get_reward(g["x"], g["xp"], g["y"], g["mask"], R, disc, max_len=T, bias_num=0.6, uniforms=g["u"],
+                      return_details=True)
+    assert np.array_equal(m.last_details["rollouts"], det["rollouts"])
+    errt = float(np.abs(rt - g["rewards_bias06"])[cells].max())
+    print("C1 fp32 reward abs err, table form %.3g" % errt)
+    assert errt < 1e-5
+    m.conv_table = 0
     # the fp16 tier on the same inputs: finite, masked, in range, and the same reward on average (single rollouts
     # diverge from the oracle's after a near-tie flip, so element-wise agreement is not expected at rollnum 4)
     m16, d16 = make_gpu_pair(gcfg, dcfg, Wg, Wd, "fp16", T)
