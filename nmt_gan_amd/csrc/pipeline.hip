@@ -767,14 +767,16 @@ static int carve_reward(Arena& ar, const nmtgan_generator* g, const nmtgan_discr
     b.win_vals = ar.get<float>(wrows * d->Fp);
     b.win_pm = ar.get<float>((int64_t)p->B * p->T * d->Fp);
   }
-  // table form: on by default (NMTGAN_CONV_TABLE=0 or plan.conv_table < 0 switch it off) when the tables fit the cap
+  // Table form of the rollouts' conv (NMTGAN_CONV_TABLE=0 or plan.conv_table < 0 switch it off; it needs the give
+  // points on the host like the prefix reuse, and tables that fit the cap).  By default only
+  //  - when the rollouts hold at least four tokens per vocabulary entry: the tables cost one product per (vocabulary
+  //    entry, tap), the conv GEMMs one per (rollout token, tap) less what the prefix reuse saves;
+  //  - for a 16-bit or split discriminator: with fp32 operands - the parity tier - one fp32 rounding per (token, tap)
+  //    entry is a little more than the matrix cores' own accumulation loses, so that tier keeps the GEMMs unless the
+  //    plan asks for the tables.
   static const bool table_env = [] { const char* e = getenv("NMTGAN_CONV_TABLE"); return !e || atoi(e) != 0; }();
   const int64_t table_cap = p->conv_table_max_bytes > 0 ? p->conv_table_max_bytes : (int64_t)96 << 30;
   b.table = ConvTable{};
-  // (an fp32 discriminator - the parity tier - keeps the GEMM form unless the plan asks for the tables: one fp32
-  // rounding per (token, tap) entry is a little more than the matrix cores' own accumulation loses)
-  // By default only when the rollouts hold at least four tokens per vocabulary entry: the tables cost one product per
-  // (vocabulary entry, tap), the conv GEMMs one per (rollout token, tap) less what the prefix reuse saves.
   const bool table_pays = (int64_t)p->n_rows * p->T >= 4 * (int64_t)d->vocab;
   b.use_table = table_env && (p->conv_table > 0 || (p->conv_table == 0 && d->op_dtype != NMTGAN_F32 && table_pays)) &&
                 b.reuse && p->T <= TABLE_MAX_LEN && conv_table_bytes(d) <= table_cap;
