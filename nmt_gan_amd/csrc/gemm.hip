@@ -1242,7 +1242,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_ln_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) bias[j] = p.bias ? p.bias[ncol + 16 * j + fc] : 0.f;
     // GI row blocks at a time (16 residual loads of 16 bytes per lane in flight), then each 16 x 32 piece changes view
-    constexpr int GI = 8 / NJP;
+    constexpr int GI = (MT % (8 / NJP) == 0) ? 8 / NJP : 2;
     auto add_residual = [&](auto H) {
       constexpr int h = decltype(H)::value;
       f32x4 res[GI][NJP][2];
@@ -1552,14 +1552,23 @@ static int launch_ln(GemmParams p, hipStream_t st) {
   NMTGAN_CHECK_LAUNCH("gemm_ln");
   return 0;
 }
-// Eight waves on 64-row tiles.  Measured alternatives (fp16, M = 49152): the same kernel as <128, 4> - four waves, one
+// Eight waves on 64-row tiles (96-row tiles from 16 k rows on: 239 VGPRs, four stages = 152 KiB of LDS).  Measured alternatives (fp16, M = 49152): the same kernel as <128, 4> - four waves, one
 // per SIMD, 128 x 128 wave tiles, half the W re-fetch per flop - runs K = 512 / 2048 in 135 / 254 us against 83 / 196:
 // with 32 KiB of W per 64-byte k-step only three stages fit in LDS, and two stages in flight per CU do not cover the
 // L2 -> LDS latency (a lone tile takes 44 us at K = 512); <128, 8> spills inside the k-loop.  K = 2048 therefore stays
 // on the 256x256 kernel + add_layernorm (176 us).
 template <typename OpT>
 static int dispatch_ln(const GemmParams& p, hipStream_t st) {
-  if constexpr (sizeof(OpT) == 2) return launch_ln<OpT, 64, 8>(p, st);
+  if constexpr (sizeof(OpT) == 2) {
+    // 96-row tiles re-fetch the 512 W rows a third less often per row of A (the kernel runs on the L2 -> LDS fill path);
+    // they pay from about 16 k rows on (C2 sweep of the switch point: 24576 / 16384 / 12288 / 8192 rows -> projections
+    // 59.0 / 58.1 / 58.3 / 58.4 ms against 59.7 with 64-row tiles only); below that the shorter tile finishes sooner.
+    // NMTGAN_LN_BM=64|96 forces one form, NMTGAN_LN_BM96_ROWS moves the switch (a row's bits are the same in both).
+    static const int bm = [] { const char* e = getenv("NMTGAN_LN_BM"); return e ? atoi(e) : 0; }();
+    static const int rows96 = [] { const char* e = getenv("NMTGAN_LN_BM96_ROWS"); return e ? atoi(e) : 16384; }();
+    if (bm == 96 || (bm == 0 && p.M >= rows96)) return launch_ln<OpT, 96, 8>(p, st);
+    return launch_ln<OpT, 64, 8>(p, st);
+  }
   NMTGAN_FAIL(-2, "gemm: the ADDLN epilogue needs a 16-bit op dtype");
 }
 
