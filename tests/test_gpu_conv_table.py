@@ -228,3 +228,44 @@ def test_conv_table_build_and_chain_against_oracle(cuda, precision, tol):
     err = float((pooled[:, :F].double().cpu() - ref_pool).abs().max() / ref_pool.abs().max())
     print("%s table chain: pooled features rel err %.3g" % (precision, err))
     assert err < {"fp32": 1e-5, "fp16x3": 1e-5, "fp16": 3e-3, "bf16": 2e-2}[precision]
+
+
+@pytest.mark.parametrize("case", [
+    dict(T=8, widths=[1, 2, 8], nfs=[5, 33, 64], B=3, R=2, V=60, lens=[8, 1, 5]),
+    dict(T=17, widths=[3, 4, 16, 17], nfs=[130, 7, 48, 19], B=4, R=3, V=300, lens=[17, 17, 2, 9]),
+    dict(T=30, widths=[1, 7, 13, 29], nfs=[110, 170, 230, 390], B=5, R=2, V=128, lens=[30, 12, 30, 3, 21]),
+])
+def test_get_reward_table_form_equals_gemm_form_on_odd_geometries(cuda, case):
+    """Whole get_reward calls in the fp32 tier with the table form forced on against the conv GEMMs and the oracle:
+    filter widths 1, 2, T - 1 and T, filter counts that are no multiple of 4, ragged samples down to one token, a
+    vocabulary that is no power of two (the generator wants a multiple of 4).  Same rollouts; P(real) of every rollout within fp32 rounding; rewards within
+    1e-5 of the oracle's."""
+    T, B, R, V = case["T"], case["B"], case["R"], case["V"]
+    gcfg = O.GenConfig(hidden_units=64, num_blocks=2, num_heads=4, src_vocab_size=V, dst_vocab_size=V,
+                       scale_embedding=True, shared_embedding=False)
+    dcfg = O.DisConfig(max_len=T, dim_word=64, vocab_size=V, vocab_size_s=V, filter_sizes=list(case["widths"]),
+                       num_filters=list(case["nfs"]))
+    Wg, Wd = O.init_generator_weights(gcfg, 3), disc_weights(dcfg, 4)
+    rng = np.random.default_rng(T)
+    x = rng.integers(4, V, (B, T)).astype(np.int32)
+    y = rng.integers(4, V, (B, T)).astype(np.int32)
+    for b, n in enumerate(case["lens"]):
+        if n < T:
+            y[b, n - 1] = O.EOS_ID
+    yd, mask = O.deal_generated_samples(y)
+    xp = O.extend_sentence_to_maxlen(x, T)
+    u = rng.random((R, T - 1, B, T), dtype=np.float32)
+    ref = O.get_reward(O.to_torch(Wg), gcfg, O.to_torch(Wd), dcfg, x, xp, yd, mask, R, T, 0.6, u, mode="incremental")
+    m, disc = make_gpu_pair(gcfg, dcfg, Wg, Wd, "fp32", T)
+    out = {}
+    for form in (1, -1):
+        m.conv_table = form
+        r = m.get_reward(x, xp, yd, mask, R, disc, max_len=T, bias_num=0.6, uniforms=u, return_details=True)
+        out[form] = (r, m.last_details)
+    n = out[1][1]["plan"].n_rows
+    assert np.array_equal(out[1][1]["rollouts"], out[-1][1]["rollouts"])
+    dp = float(np.abs(out[1][1]["p_rows"][:n] - out[-1][1]["p_rows"][:n]).max()) if n else 0.0
+    print("T=%d: %d rollouts, max |dP(real)| table vs GEMM form %.3g" % (T, n, dp))
+    assert dp < 5e-6
+    for form in (1, -1):
+        assert np.abs(out[form][0] - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), form
