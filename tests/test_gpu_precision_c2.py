@@ -37,7 +37,9 @@ PEAK = 5.0
 
 # measured on MI355X; asserted with margin.  Measured: fp16 logits 9.0e-4 (both vehicles), bf16 7.4e-3; token agreement
 # fp16 90.7 % / 91.7 %, bf16 66.4 % / 81.4 % (reference-init / trained-like); max |dP(real)| fp16 2.7e-2 / 1.6e-4, bf16
-# 2.0e-1 / 1.3e-3; rewards (inf-norm, relative) fp16 4.4e-3 / 4.7e-4, bf16 3.9e-2 / 5.2e-3.
+# 2.0e-1 / 1.3e-3; rewards (inf-norm, relative) fp16 4.4e-3 / 4.7e-4, bf16 3.9e-2 / 5.2e-3 (conv GEMMs; with the table form
+# of the rollouts' conv, the default at this size: max |dP(real)| fp16 2.9e-2 / 1.8e-4, bf16 1.9e-1 / 1.5e-3, rewards fp16
+# 6.2e-3 / 5.7e-4, bf16 2.1e-2 / 4.7e-3; fp16x3 3.0e-4 / 1.6e-6 and 5.6e-5 / 5.1e-6).
 # Against the north star (1e-3 logits and rewards, 99.5 % tokens): fp16 meets the logits bound on both vehicles and the
 # reward bound with a discriminator whose BatchNorm statistics fit its activations; NO 16-bit tier reaches 99.5 % token
 # agreement at V = 32000 - at a logit error of 1e-3 about one draw in eleven is a near-tie there - only the fp32 tier and
