@@ -269,3 +269,28 @@ def test_conv_table_and_gemm_form_agree(cuda, setup, precision):
         err = np.abs(out[form]["p_rows"][:n] - p_ref).max()
         print("%s conv form %d: P(real) abs err %.3g" % (precision, form, err))
         assert err < p_tol, (form, err)
+
+
+def test_conv_table_follows_the_discriminator_weights_and_the_size_cap(cuda, setup):
+    """The per-(token, tap) tables live inside one call: a discriminator whose weights change between two get_reward
+    calls (gan_train.py trains it there) is scored with its NEW weights - same bits as a fresh DisCNN holding them -
+    and a table budget too small for the tables sends the call through the conv GEMMs (the bits of conv_table = -1)."""
+    s = setup
+    m, disc = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], s["Wd"], "fp16x3", T)
+    m.conv_table = 1
+    kw = dict(max_len=T, bias_num=0.6, uniforms=s["u"], return_details=True)
+    r_old = m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, disc, **kw)
+    Wd2 = disc_weights(s["dcfg"], 7)
+    disc.load_weights(Wd2)                                  # same object, new weights
+    r_new = m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, disc, **kw)
+    p_new = m.last_details["p_rows"].copy()
+    _, fresh = make_gpu_pair(s["gcfg"], s["dcfg"], s["Wg"], Wd2, "fp16x3", T)
+    r_fresh = m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, fresh, **kw)
+    assert np.array_equal(r_new, r_fresh) and np.array_equal(p_new, m.last_details["p_rows"])
+    assert np.abs(r_new - r_old).max() > 1e-3               # the two discriminators do score differently
+    m.conv_table = -1
+    r_gemm = m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, fresh, **kw)
+    p_gemm = m.last_details["p_rows"].copy()
+    m.conv_table, m.conv_table_max_bytes = 1, 4096          # forced on, but the tables do not fit 4 KiB
+    r_cap = m.get_reward(s["x"], s["xp"], s["y"], s["mask"], R, fresh, **kw)
+    assert np.array_equal(r_cap, r_gemm) and np.array_equal(m.last_details["p_rows"], p_gemm)

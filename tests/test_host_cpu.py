@@ -453,3 +453,22 @@ def test_bench_tier_flags_come_from_the_tracked_accuracy_records():
     f32 = bench.tier_accuracy("fp32")
     assert f32["tolerance"]["logits_rel"] == 1e-5 and f32["meets_north_star"]["logits"] and f32["meets_north_star"]["tokens"]
     assert bench.tier_accuracy("no-such-tier") is None
+
+
+def test_bench_table_gather_bytes_match_a_direct_count():
+    """bench.py prices the table form of the conv by the bytes it has to gather; the closed loop over give points in
+    bench.table_gather_bytes equals a direct walk over every (rollout, width, window, tap)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    T, widths, nfs = 11, [1, 3, 4, 10, 11], [7, 12, 5, 9, 20]
+    row_g = np.array([1, 1, 2, 5, 5, 5, 9, 10], np.int64)
+    for tes in (2, 4):
+        want = 0
+        for g in row_g:
+            for w, n in zip(widths, nfs):
+                for q in range(T - w + 1):
+                    if q + w <= g:
+                        continue                                   # window inside the prefix: from the prefix max
+                    own = sum(1 for j in range(w) if q + j >= g)   # taps that hold the rollout's own tokens
+                    want += own * n * tes + (n * 4 if q < g else 0)  # + one fp32 partial-sum row when it straddles
+        assert bench.table_gather_bytes(T, widths, nfs, row_g, tes) == want
