@@ -1,0 +1,116 @@
+"""The oracle's building blocks against an independent implementation of the same standard operators: PyTorch's own
+layer_norm, scaled_dot_product_attention, conv2d + batch_norm, linear layers, Adam and Adadelta.  The reference cannot
+run here (Python 2 + TensorFlow 1.2) and ships no fixtures, so nothing pins the oracle to the reference itself; this
+file at least pins every operator the oracle restates by hand to a second code base that was written without it -
+a slip in a hand-written softmax, variance, window layout or optimizer formula shows up here."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import nmtgan_oracle as O
+
+torch.manual_seed(0)
+
+
+def test_layer_norm_is_the_library_layer_norm_with_eps_1e6():
+    x = torch.randn(5, 7, 64, dtype=torch.float64) * 3 + 1
+    W = {"n/layer_norm_scale": torch.randn(64, dtype=torch.float64), "n/layer_norm_bias": torch.randn(64, dtype=torch.float64)}
+    want = F.layer_norm(x, (64,), W["n/layer_norm_scale"], W["n/layer_norm_bias"], eps=1e-6)       # common_layers.py:359-374
+    assert torch.allclose(O._layer_norm(x, W, "n"), want, rtol=0, atol=1e-12)
+
+
+def test_attention_is_scaled_dot_product_attention_over_split_heads():
+    """common_attention.py:294-331, 389-396: q scaled by dk^-0.5, additive bias, softmax over keys, heads recombined -
+    with a causal bias, with a padding bias, and without any."""
+    B, Lq, Lk, d, h = 3, 6, 9, 32, 4
+    q, k, v = (torch.randn(B, L, d, dtype=torch.float64) for L in (Lq, Lk, Lk))
+    pad = torch.zeros(B, 1, 1, Lk, dtype=torch.float64)
+    pad[1, ..., 7:] = -1e9
+    pad[2, ..., 3:] = -1e9
+    causal = torch.full((Lq, Lq), -1e9, dtype=torch.float64).triu(1)[None, None]
+    split = lambda t: t.view(B, t.shape[1], h, d // h).transpose(1, 2)
+    for bias, kk, vv in ((None, k, v), (pad, k, v), (causal, k[:, :Lq], v[:, :Lq])):
+        got = O._attend(q, kk, vv, bias, h)
+        ref = F.scaled_dot_product_attention(split(q), split(kk), split(vv), attn_mask=bias, scale=(d // h) ** -0.5)
+        assert torch.allclose(got, ref.transpose(1, 2).reshape(B, Lq, d), rtol=0, atol=1e-12)
+
+
+def test_conv_tower_is_conv2d_batchnorm_relu_maxpool():
+    """cnn_discriminator.py:88-109, 22-33, 469: VALID conv over [T, E] windows of width w, bias, inference BatchNorm
+    (eps 1e-3), ReLU, max over time - against F.conv2d / F.batch_norm on the NCHW image."""
+    dcfg = O.DisConfig(max_len=13, dim_word=16, vocab_size=50, vocab_size_s=50, filter_sizes=[1, 4, 13], num_filters=[6, 9, 5])
+    Wd = O.to_torch(O.init_disc_weights(dcfg, 3))
+    e = torch.randn(4, 13, 16, dtype=torch.float64)
+    for w in dcfg.filter_sizes:
+        s = "discnn/conv_maxpool-%d" % w
+        got = O._conv_bn_relu_max(e, Wd, s)
+        kern = Wd[s + "/self_model/W"].permute(3, 2, 0, 1)                    # [w, E, 1, n] -> [n, 1, w, E]
+        c = F.conv2d(e[:, None], kern, Wd[s + "/self_model/b"])              # [B, n, T-w+1, 1]
+        bn = s + "/conv_batch_norm/bn/"
+        c = F.batch_norm(c, Wd[bn + "moving_mean"], Wd[bn + "moving_variance"], Wd[bn + "gamma"], Wd[bn + "beta"],
+                         training=False, eps=1e-3)
+        want = torch.relu(c).amax(dim=(2, 3))
+        assert torch.allclose(got, want, rtol=0, atol=1e-12), w
+
+
+def test_dense_ffn_and_highway_are_linear_layers():
+    x = torch.randn(3, 5, 8, dtype=torch.float64)
+    W = {"f/conv1_single/kernel": torch.randn(8, 32, dtype=torch.float64), "f/conv1_single/bias": torch.randn(32, dtype=torch.float64),
+         "f/conv2_single/kernel": torch.randn(32, 8, dtype=torch.float64), "f/conv2_single/bias": torch.randn(8, dtype=torch.float64)}
+    want = F.linear(torch.relu(F.linear(x, W["f/conv1_single/kernel"].T, W["f/conv1_single/bias"])),
+                    W["f/conv2_single/kernel"].T, W["f/conv2_single/bias"])                       # common_layers.py:1078-1109
+    assert torch.allclose(O._ffn(x, W, "f"), want, rtol=0, atol=1e-12)
+    H = torch.randn(6, 10, dtype=torch.float64)
+    Wh = {"o/weights": torch.randn(10, 10, dtype=torch.float64), "t/weights": torch.randn(10, 10, dtype=torch.float64)}
+    t = torch.sigmoid(F.linear(H, Wh["t/weights"].T))
+    want = t * torch.relu(F.linear(H, Wh["o/weights"].T)) + (1 - t) * H                            # cnn_discriminator.py:50-59
+    assert torch.allclose(O._highway(H, Wh, "o", "t"), want, rtol=0, atol=1e-12)
+
+
+def test_cdf_sampler_is_searchsorted_on_the_cumulative_softmax():
+    """tf.multinomial's CPU kernel as the oracle restates it (model.py:235-241): first index whose fp64 CDF exceeds
+    u * total - the same bucket torch.searchsorted finds on the normalised cumulative softmax."""
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        logits = (rng.standard_normal(97) * 3).astype(np.float32)
+        u = float(rng.random())
+        cdf = torch.cumsum(torch.softmax(torch.from_numpy(logits).double(), 0), 0)
+        want = int(torch.searchsorted(cdf, torch.tensor(u, dtype=torch.float64), right=True).clamp(max=96))
+        assert O.multinomial_cdf(logits, np.float32(u)) == want or abs(float(cdf[min(want, 96)]) - u) < 1e-9
+
+
+def _run_torch_opt(opt_cls, W0, grads, **kw):
+    p = {k: torch.nn.Parameter(torch.from_numpy(v.copy())) for k, v in W0.items()}
+    opt = opt_cls(list(p.values()), **kw)
+    for G in grads:
+        for k in p:
+            p[k].grad = torch.from_numpy(G[k].copy())
+        opt.step()
+    return {k: v.detach().numpy() for k, v in p.items()}
+
+
+def test_adam_and_adadelta_steps_are_the_library_optimizers():
+    """The update rules the oracle restates from TF 1.x (cnn_discriminator.py:153-155 AdamOptimizer(), model.py:115-116
+    AdadeltaOptimizer()) against torch.optim over three steps.  TF folds Adam's bias corrections into the step size and
+    keeps epsilon outside them (epsilon-hat form): the two forms differ by a factor 1 + O(epsilon / |g| sqrt(1 - beta2^t)),
+    1e-5 of a step of 1e-3 here."""
+    rng = np.random.default_rng(5)
+    W0 = {"a": rng.standard_normal((4, 3)), "b": rng.standard_normal(7)}
+    grads = [{k: rng.standard_normal(v.shape) for k, v in W0.items()} for _ in range(3)]
+    W = {k: v.copy() for k, v in W0.items()}
+    m = {k: np.zeros_like(v) for k, v in W.items()}
+    v_ = {k: np.zeros_like(v) for k, v in W.items()}
+    for t, G in enumerate(grads, 1):
+        O.adam_apply(W, G, m, v_, t)
+    ref = _run_torch_opt(torch.optim.Adam, W0, grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    for k in W:
+        assert np.allclose(W[k], ref[k], rtol=0, atol=2e-7)
+        assert np.abs(W[k] - W0[k]).max() > 2e-3               # three full steps were taken
+    W = {k: v.copy() for k, v in W0.items()}
+    acc = {k: np.zeros_like(v) for k, v in W.items()}
+    upd = {k: np.zeros_like(v) for k, v in W.items()}
+    for G in grads:
+        O.adadelta_apply(W, G, acc, upd, lr=1.0, rho=0.95, epsilon=1e-6)
+    ref = _run_torch_opt(torch.optim.Adadelta, W0, grads, lr=1.0, rho=0.95, eps=1e-6)
+    for k in W:
+        assert np.allclose(W[k], ref[k], rtol=0, atol=1e-12)
