@@ -114,3 +114,14 @@ def test_adam_and_adadelta_steps_are_the_library_optimizers():
     ref = _run_torch_opt(torch.optim.Adadelta, W0, grads, lr=1.0, rho=0.95, eps=1e-6)
     for k in W:
         assert np.allclose(W[k], ref[k], rtol=0, atol=1e-12)
+
+
+def test_timing_signal_is_the_tensor2tensor_layout_other_libraries_implement():
+    """common_attention.py:57-93 (get_timing_signal_1d: log-spaced timescales, all sines then all cosines): the
+    `transformers` library ships the same layout for fairseq-style models and says so in its source ("matches the
+    implementation in tensor2tensor"); it computes in fp32."""
+    import pytest
+    m2m = pytest.importorskip("transformers.models.m2m_100.modeling_m2m_100")
+    for length, channels in ((50, 64), (80, 512)):
+        ref = m2m.M2M100SinusoidalPositionalEmbedding.get_embedding(length, channels, None).double().numpy()
+        assert np.abs(O.timing_signal(length, channels) - ref).max() < 1e-5
