@@ -124,4 +124,4 @@ def test_timing_signal_is_the_tensor2tensor_layout_other_libraries_implement():
     m2m = pytest.importorskip("transformers.models.m2m_100.modeling_m2m_100")
     for length, channels in ((50, 64), (80, 512)):
         ref = m2m.M2M100SinusoidalPositionalEmbedding.get_embedding(length, channels, None).double().numpy()
-        assert np.abs(O.timing_signal(length, channels) - ref).max() < 1e-5
+        assert np.abs(O.timing_signal(length, channels) - ref).max() < 5e-5      # fp32 sines of arguments up to 79
