@@ -125,3 +125,27 @@ def test_timing_signal_is_the_tensor2tensor_layout_other_libraries_implement():
     for length, channels in ((50, 64), (80, 512)):
         ref = m2m.M2M100SinusoidalPositionalEmbedding.get_embedding(length, channels, None).double().numpy()
         assert np.abs(O.timing_signal(length, channels) - ref).max() < 5e-5      # fp32 sines of arguments up to 79
+
+
+def test_rmsprop_step_is_the_library_optimizer_started_from_ones():
+    """tf.train.RMSPropOptimizer(lr) as the oracle restates it (model.py:119: decay 0.9, momentum 0, epsilon 1e-10 inside
+    the square root, mean-square slot initialised to ONES) against torch.optim.RMSprop with its slot preset to ones;
+    the two place epsilon differently (inside / outside the root), 1e-10 of a mean square that never falls below 0.7 here."""
+    rng = np.random.default_rng(6)
+    W0 = {"a": rng.standard_normal((5, 2)), "b": rng.standard_normal(3)}
+    grads = [{k: rng.standard_normal(v.shape) for k, v in W0.items()} for _ in range(3)]
+    W = {k: v.copy() for k, v in W0.items()}
+    ms = {k: np.ones_like(v) for k, v in W.items()}
+    for G in grads:
+        O.rmsprop_apply(W, G, ms, lr=1e-3)
+    p = {k: torch.nn.Parameter(torch.from_numpy(v.copy())) for k, v in W0.items()}
+    opt = torch.optim.RMSprop(list(p.values()), lr=1e-3, alpha=0.9, eps=1e-10, momentum=0.0, centered=False)
+    for q in p.values():
+        opt.state[q] = {"step": torch.tensor(0.0), "square_avg": torch.ones_like(q)}
+    for G in grads:
+        for k in p:
+            p[k].grad = torch.from_numpy(G[k].copy())
+        opt.step()
+    for k in W:
+        assert np.allclose(W[k], p[k].detach().numpy(), rtol=0, atol=1e-12)
+        assert np.abs(W[k] - W0[k]).max() > 1e-3
