@@ -149,3 +149,30 @@ def test_rmsprop_step_is_the_library_optimizer_started_from_ones():
     for k in W:
         assert np.allclose(W[k], p[k].detach().numpy(), rtol=0, atol=1e-12)
         assert np.abs(W[k] - W0[k]).max() > 1e-3
+
+
+def test_training_mode_conv_tower_and_loss_are_the_library_ops():
+    """The discriminator's training graph as the oracle restates it (cnn_discriminator.py:88-109, 282-283, 323):
+    batch-moment BatchNorm over (batch, time) with a biased variance and eps 1e-3 - F.batch_norm(training=True) on the
+    NCHW conv output, whose running-statistics update also reports the batch mean - and the per-example softmax
+    cross-entropy against one-hot labels - F.cross_entropy(reduction='none')."""
+    dcfg = O.DisConfig(max_len=11, dim_word=8, vocab_size=40, vocab_size_s=40, filter_sizes=[2, 5], num_filters=[6, 4])
+    Wd = O.to_torch(O.init_disc_weights(dcfg, 9))
+    e = torch.randn(7, 11, 8, dtype=torch.float64)
+    for w in dcfg.filter_sizes:
+        s = "discnn/conv_maxpool-%d" % w
+        stats = {}
+        got = O._conv_bn_train_relu_max(e, Wd, s, stats)
+        c = F.conv2d(e[:, None], Wd[s + "/self_model/W"].permute(3, 2, 0, 1), Wd[s + "/self_model/b"])
+        bn = s + "/conv_batch_norm/bn/"
+        run_mean, run_var = torch.zeros(c.shape[1], dtype=torch.float64), torch.ones(c.shape[1], dtype=torch.float64)
+        out = F.batch_norm(c, run_mean, run_var, Wd[bn + "gamma"], Wd[bn + "beta"], training=True, momentum=1.0, eps=1e-3)
+        assert torch.allclose(got, torch.relu(out).amax(dim=(2, 3)), rtol=0, atol=1e-12)
+        assert torch.allclose(stats[s][0], run_mean, rtol=0, atol=1e-12)        # momentum 1: running mean = batch mean
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 40, (11, 5))
+    xs = rng.integers(0, 40, (11, 5))
+    labels = rng.integers(0, 2, 5)
+    y = np.eye(2)[labels].T                                                    # [2, B] one-hot, as train() feeds it
+    losses, scores, _ = O.disc_train_loss(Wd, dcfg, x, xs, y)
+    assert torch.allclose(losses, F.cross_entropy(scores, torch.from_numpy(labels), reduction="none"), rtol=0, atol=1e-12)
