@@ -16,7 +16,12 @@ source does not show (recalled from upstream TF 1.x, unverifiable offline):
   * contrib `batch_norm` inference form, epsilon=0.001 -> `_conv_bn_relu_max`
   * `tf.layers.conv2d` has a bias (use_bias=True)      -> `_dense`
 The goldens under tests/golden/ were produced by THIS file (fp64) and pin it
-against regressions only.
+against regressions only.  The hand-written operators below (layer norm, attention,
+conv + batch norm + pool, feed-forward / highway blocks, CDF sampler, timing signal,
+training-mode batch norm, cross-entropy, RMSProp / Adadelta / Adam) are checked
+against PyTorch's and the transformers library's own implementations of the same
+standard operators in tests/test_oracle_crosscheck_cpu.py - a guard against slips in
+the formulas, not a substitute for the reference's outputs.
 
 Each function cites the reference file:line it follows (paths relative to
 /root/reference).  Two decoding modes are provided:
