@@ -261,3 +261,53 @@ def test_two_ranks_sharded_get_reward_equals_unsharded(cuda, tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o[-3000:]
         assert "rank %d ok" % r in o
+
+
+_RCCL_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root)
+from nmt_gan_amd.model import gather_rows
+from nmt_gan_amd.share_function import split_bounds
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+print("group up", flush=True)
+T, B = 12, 7
+bounds = split_bounds(B, 1)
+cache = {}
+a = torch.arange(B * T, dtype=torch.float32, device=dev).reshape(B, T)
+g1 = gather_rows(a, bounds, dev, cache)                       # device tensors straight into the collective
+assert g1.is_cuda and torch.equal(g1, a)
+view = gather_rows(a, bounds, dev, cache, copy=False)         # a view of the cached receive buffer
+assert torch.equal(view, a)
+b = a * 2
+g2 = gather_rows(b, bounds, dev, cache)
+assert torch.equal(g2, b) and torch.equal(g1, a), "a copied result must survive the next call"
+assert g1.data_ptr() != g2.data_ptr() and len(cache) == 1
+t = torch.full((4,), 3.0, dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.sum().item()) == 12.0
+torch.cuda.synchronize(dev)
+dist.barrier()
+torch.cuda.synchronize(dev)
+dist.destroy_process_group()
+print("rccl ok", flush=True)
+'''
+
+
+def test_rccl_backend_one_rank_gather(cuda, tmp_path):
+    """The collective calls of the N > 1 path on the RCCL backend itself (the two-rank tests run gloo, because two ranks
+    cannot share one GPU under RCCL): a one-rank group on cuda:0 takes gather_rows down its device-tensor branch, and
+    the timing all-reduce and barrier of bench.py run as they do at N > 1."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    port = str(31600 + os.getpid() % 2000)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.Popen([sys.executable, "-u", str(script), ROOT, port], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT)
+    out = p.communicate(timeout=240)[0].decode()
+    assert p.returncode == 0, out[-3000:]
+    assert "rccl ok" in out
