@@ -359,6 +359,9 @@ int nmtgan_disc_head(const nmtgan_discriminator* d, const float* feat_t, const f
  * the prefix, or zeros; col_i = filters of the widths before i).  Entries are `dtype` (NMTGAN_F16 / BF16 / F32; fp32
  * entries are added in fp64), S is fp32, nfp[i] >= nf[i] pads a table row to whole 16-byte vectors (the library uses
  * 128-byte lines); every table 16-byte aligned.  wt[i] is scratch of the build: w*nfp operand rows of the discriminator.
+ * Token ids are clamped to [0, vocab) on the device; row_b[r] must name a sentence of the preceding
+ * nmtgan_conv_table_prefix call (0 <= row_b[r] < B: it indexes S, which the kernels cannot bound) and row_g[r] the row's
+ * give point, 1 <= row_g[r] <= T (a row whose give point is T has no window of its own and keeps pooled as passed).
  */
 typedef struct {
   int n_widths, T, Fp, vocab, dtype;
