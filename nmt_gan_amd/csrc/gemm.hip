@@ -1614,6 +1614,33 @@ static bool prefer_p8_linear(int64_t M, int N, int nkt) {
   const int64_t rounds_pipe = (rt * ((N + 127) / 128) + cus - 1) / cus, rounds_p8 = (rt * ((N + 255) / 256) + cus - 1) / cus;
   return (double)rounds_p8 * (13.3 + 1.21 * nkt) < (double)rounds_pipe * (5.7 + 0.854 * nkt);
 }
+// LINEAR epilogue over plain rows, 16-bit operands: a problem that fills the CUs r times with 256x256 tiles and then
+// leaves a last round mostly empty (N = 512, M = 49152: 384 tiles on 256 CUs) is cut by rows - the first m1 rows are
+// r FULL rounds of the 256x256 kernel, the remainder goes back through the kernel choice on its own (usually one round
+// of 256x128 tiles).  Priced with the same rounds model as prefer_p8_linear plus a charge for the extra launch; returns
+// m1 or 0.  An output element's k order is the same in both kernels, so the cut changes no bits.
+// NMTGAN_GEMM_ROWSPLIT=0 switches it off.
+static int64_t p8_row_split(int64_t M, int N, int nkt) {
+  static const bool on = [] { const char* e = getenv("NMTGAN_GEMM_ROWSPLIT"); return !e || atoi(e) != 0; }();
+  if (!on || p8_mode() != 1 || nkt < 4) return 0;
+  const int64_t cus = persistent_grid(1 << 30);
+  const int64_t ntn8 = (N + 255) / 256, ntnp = (N + 127) / 128;
+  const int64_t rows_round = (cus / ntn8) * 256;
+  if (rows_round <= 0 || M <= rows_round) return 0;
+  const double t8 = 13.3 + 1.21 * nkt, tp = 5.7 + 0.854 * nkt, launch = 6.0;
+  auto whole = [&](int64_t m) {
+    const int64_t rt = (m + 255) / 256;
+    return std::min((double)((rt * ntn8 + cus - 1) / cus) * t8, (double)((rt * ntnp + cus - 1) / cus) * tp);
+  };
+  double best = whole(M) - 1.0;                  // a cut has to win by more than a microsecond
+  int64_t m1 = 0;
+  for (int64_t r = 1; r * rows_round < M; ++r) {
+    const double c = (double)r * t8 + whole(M - r * rows_round) + launch;
+    if (c < best) { best = c; m1 = r * rows_round; }
+  }
+  return m1;
+}
+
 template <typename OpT, int EPI>
 static int dispatch(const GemmParams& p, hipStream_t st) {
   const int ov = tile_override();
@@ -1641,6 +1668,24 @@ static int dispatch(const GemmParams& p, hipStream_t st) {
     }
   }
   const bool modelled = EPI == NMTGAN_EPI_LINEAR && sizeof(OpT) == 2 && tiles256 >= 16 && p8_mode() != 3;
+  if constexpr (EPI == NMTGAN_EPI_LINEAR) {
+    if (modelled && pipe_ok && ov < 0 && p.a_group == 0) {
+      const int64_t m1 = p8_row_split(p.M, p.N, nkt);
+      if (m1 > 0) {
+        GemmParams a = p, b = p;
+        a.M = (int)m1;
+        b.M = p.M - (int)m1;
+        b.A = p.A + m1 * p.lda_b;
+        for (int sgm = 0; sgm < 3; ++sgm) {
+          if (!p.out[sgm]) continue;
+          const int64_t oes = p.out_f32[sgm] == 1 ? 4 : (p.out_f32[sgm] == 2 ? 2 : (int64_t)sizeof(OpT));
+          b.out[sgm] = (char*)p.out[sgm] + m1 * p.ldo[sgm] * oes;
+        }
+        NMTGAN_TRY((launch_p8<OpT, EPI>(a, st)));
+        return dispatch<OpT, EPI>(b, st);
+      }
+    }
+  }
   if (pipe_ok && (modelled ? prefer_p8_linear(p.M, p.N, nkt) : prefer_p8(p.M, p.N, nkt))) return launch_p8<OpT, EPI>(p, st);
   static const int pipe_min_tiles = [] { const char* e = getenv("NMTGAN_PIPE_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
   if (pipe_ok && (ov == 3 || (ov < 0 && tiles256 >= pipe_min_tiles))) return launch_pipe<OpT, EPI>(p, st);

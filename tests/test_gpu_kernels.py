@@ -96,6 +96,36 @@ def test_gemm_persistent_many_tiles(cuda, op, M, N, K, relu):
     assert worst < tol, (worst, tol)
 
 
+@pytest.mark.parametrize("op", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K,f32_out,relu", [(49152, 512, 2048, True, 0), (40960, 512, 2048, True, 0),
+                                                 (45056, 2048, 512, False, 1), (33792, 512, 1536, True, 0)])
+def test_gemm_row_cut_same_bits(cuda, op, M, N, K, f32_out, relu):
+    """Row counts at which the kernel choice cuts a LINEAR problem by rows (full rounds of 256x256 tiles first, the
+    remainder on its own): every row must carry the bits it gets when its 8192-row block is a problem of its own - the
+    cut moves operand and output pointers and may hand the two parts to different kernels - and the whole result is
+    checked against a float64 product."""
+    L = _lib()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dt = _TD[op]
+    A = (torch.rand(M, K, generator=g) * 2 - 1).to(dt).to(cuda)
+    Wt = (torch.rand(N, K, generator=g) * 2 - 1 + torch.arange(N)[:, None] * 1e-4).to(dt).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    (out,) = _gemm(L, A, Wt, bias=bias, relu=relu, op=op, segs=[(N, f32_out, 1.0)])
+    worst, scale = 0.0, 0.0
+    for r0 in range(0, M, 8192):
+        blk = A[r0:r0 + 8192]
+        (part,) = _gemm(L, blk, Wt, bias=bias, relu=relu, op=op, segs=[(N, f32_out, 1.0)])
+        assert torch.equal(part, out[r0:r0 + 8192]), r0
+        ref = blk.double() @ Wt.double().T + bias.double()
+        if relu:
+            ref = torch.relu(ref)
+        worst = max(worst, (part.double() - ref).abs().max().item())
+        scale = max(scale, ref.abs().max().item())
+    # fp32 outputs: accumulation order only; 16-bit outputs: one rounding of the stored value (2^-8 covers bf16)
+    tol = 2e-6 * K ** 0.5 * (K / 3) ** 0.5 + 1e-5 if f32_out else scale * 2.0 ** -8
+    assert worst < tol, (worst, tol)
+
+
 @pytest.mark.parametrize("op", ["bf16", "fp16"])
 def test_gemm_segments_and_scale(cuda, op):
     L = _lib()
