@@ -287,9 +287,12 @@ __global__ __launch_bounds__(256) void attn_rows_16_kernel(AttnParams p) {
 // that the instruction stream of a wave is arithmetic and loads: the compiled loop of the kernel above spends 83 scalar
 // instructions per key (each `if (valid)` on a wave-uniform flag becomes an EXEC-mask sequence and a branch, every key
 // offset a 64-bit scalar multiply, the head reduction six run-time tests) beside 53 vector instructions; this one 22 and
-// 34.  The keys of both segments form ONE sequence of batches; a batch always loads KB keys (indices clamped to the
-// segment's last key, so the tail re-reads a valid key) and an invalid slot only gets its score replaced by -inf, which
-// makes its weight exactly 0: the sums, the running maximum and the output are the bits of the kernel above.
+// 34.  Each segment is cut into batches of KB keys on its own (first the prefix, then the suffix); a batch always loads
+// KB keys (indices clamped to the segment's last key, so the tail re-reads a valid key) and an invalid slot only gets
+// its score replaced by -inf, which makes its weight exactly 0.  The kernel above batches the concatenated sequence,
+// so when the prefix length is no multiple of KB the two rescale the running sums at different keys and differ in the
+// last place of the stored value (tests/test_gpu_kernels.py compares them at that level); which kernel a call takes
+// depends on its mask argument and shape alone, never on the batch, so a row's bits are still a function of the row.
 // (Worth 2 % of the kernel's time, no more: it waits on memory either way - two-key batches at seven waves per SIMD
 // instead of four-key batches at four run the same.)
 // d = 64 EPL and the lanes per head (LPH = 64 / heads) are compile-time values: key offsets are shifts instead of

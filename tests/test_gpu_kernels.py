@@ -509,6 +509,68 @@ def test_attn_rows_two_segments(cuda, kv, d, heads, q_op):
         assert err < {"bf16": 2e-2, "fp16": 3e-3, "fp32": 2e-5}[kv], (r, err)   # 16-bit: output rounding only
 
 
+@pytest.mark.parametrize("kv,q_op", [("fp16", 1), ("fp16", 0), ("bf16", 1), ("fp32", 0)])
+@pytest.mark.parametrize("d,heads", [(512, 8), (1024, 16)])
+def test_attn_rows_mask_free_kernels(cuda, kv, q_op, d, heads):
+    """Calls without a padding mask take kernels of their own at d = 512 / 1024 (the rollout steps' self-attention), checked
+    against a float64 softmax for every mix of prefix and suffix lengths around the batch size of four keys, and against
+    the general kernels, which an all-zero mask selects.  The two forms round differently in the last place - the 16-bit
+    kernel batches each segment on its own, so a prefix length that is no multiple of four moves the rescaling points of
+    the online softmax, and the branch-free fp32 kernel lets the compiler fuse l * alpha + w where the general kernel's
+    branches keep the two apart - so they are compared at one rounding step of the stored value; the fp32 kernel also as
+    the split-precision operand image (hi + lo)."""
+    L = _lib()
+    g = torch.Generator().manual_seed(d + heads + q_op)
+    dt = _TD[kv]
+    nblk, len1, M, nsteps = 5, 11, 37, 6
+    q = (torch.randn(M, d, generator=g) * 0.3).to(cuda)
+    if q_op:
+        q = q.to(dt)
+    k1 = torch.randn(nblk, len1, d, generator=g).to(dt).to(cuda)
+    v1 = torch.randn(nblk, len1, d, generator=g).to(dt).to(cuda)
+    blk = torch.randint(0, nblk, (M,), generator=g, dtype=torch.int32).to(cuda)
+    cnt = torch.randint(1, len1 + 1, (M,), generator=g, dtype=torch.int32).to(cuda)
+    zero_mask = torch.zeros(nblk, len1, dtype=torch.uint8, device=cuda)
+    live = [M, M - 1, M - 1, M - 4, M - 9, M - 9]
+    step_off = torch.tensor(np.concatenate([[0], np.cumsum(live)]).astype(np.int64)).to(cuda)
+    k2 = torch.randn(int(sum(live)), d, generator=g).to(dt).to(cuda)
+    v2 = torch.randn(int(sum(live)), d, generator=g).to(dt).to(cuda)
+    so = step_off.cpu().numpy()
+
+    def run(ns, mask, split):
+        rows = live[ns - 1] if ns > 0 else M
+        out = torch.full((rows, 3 * d if split else d), float("nan"), device=cuda, dtype=torch.float16 if split else dt)
+        a = L.AttnArgs()
+        a.q, a.M, a.d, a.heads, a.q_op_dtype = q.data_ptr(), rows, d, heads, q_op
+        a.kv_dtype = _code(L, kv)
+        a.k1, a.v1, a.len1 = k1.data_ptr(), v1.data_ptr(), len1
+        a.seg1_blk, a.seg1_cnt = blk.data_ptr(), cnt.data_ptr()
+        a.mask1 = None if mask is None else mask.data_ptr()
+        if ns > 0:
+            a.k2, a.v2, a.step_off, a.n_steps2 = k2.data_ptr(), v2.data_ptr(), step_off.data_ptr(), ns
+        a.out, a.out_split = out.data_ptr(), int(split)
+        L.check(L.lib.nmtgan_attn_rows(C.byref(a), L.stream_ptr()))
+        torch.cuda.synchronize()
+        return out
+
+    for ns in range(0, nsteps + 1):
+        lean, general = run(ns, None, False), run(ns, zero_mask, False)
+        gap = (lean.double() - general.double()).abs().max().item()
+        assert gap <= {"bf16": 2.0 ** -6, "fp16": 2.0 ** -9, "fp32": 2e-6}[kv], (ns, gap)   # one rounding step of the stored value
+        if kv == "fp32":
+            img_l, img_g = run(ns, None, True).double(), run(ns, zero_mask, True).double()
+            assert torch.equal(img_l[:, :d], img_l[:, 2 * d:]) and torch.equal(img_g[:, :d], img_g[:, 2 * d:])
+            assert ((img_l[:, :d] + img_l[:, d:2 * d]) - lean.double()).abs().max().item() <= 2.0 ** -20
+            assert ((img_l[:, :d] + img_l[:, d:2 * d]) - (img_g[:, :d] + img_g[:, d:2 * d])).abs().max().item() <= 2e-6
+        for r in range(0, lean.shape[0], 5):
+            b, c = int(blk[r]), int(cnt[r])
+            ks = [k1[b, j] for j in range(c)] + [k2[so[t] + r] for t in range(ns)]
+            vs = [v1[b, j] for j in range(c)] + [v2[so[t] + r] for t in range(ns)]
+            ref = _attn_ref(q[r].double().cpu(), torch.stack(ks).double().cpu(), torch.stack(vs).double().cpu(), heads)
+            err = (lean[r].double().cpu() - ref).abs().max().item()
+            assert err < {"bf16": 2e-2, "fp16": 3e-3, "fp32": 2e-5}[kv], (ns, r, err)
+
+
 def test_attn_rows_causal(cuda):
     L = _lib()
     g = torch.Generator().manual_seed(5)
